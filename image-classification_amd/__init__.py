@@ -1,0 +1,11 @@
+"""image-classification_amd -- MI355X-native feature-bank similarity path.
+
+One hot path of sailist/image-classification, rebuilt for gfx950: the weighted-kNN monitor
+(``models/knn.py``) and the MoCo queue (``models/memory_bank.py``, ``track_ssl/moco.py``).
+Import as ``image_classification_amd`` (alias module at the repository root)."""
+from . import _lib
+from .knn import BankIndex, knn_merge, knn_predict, knn_predict_full, knn_topk, knn_vote, pack_rows
+from .memory_bank import MemoryBank, StorageBank
+
+__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex",
+           "pack_rows", "MemoryBank", "StorageBank", "_lib"]

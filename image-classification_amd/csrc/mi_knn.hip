@@ -1,0 +1,493 @@
+// mi_knn.hip -- C ABI (include/mi_knn.h) and host-side stage scheduling for gfx950.
+//
+// Path: models/knn.py:4-21 (similarity GEMM, top-k, vote, ranking),
+// models/memory_bank.py:58-72 (truncating ring push), track_ssl/moco.py:152-156 (queue logits).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi_knn.h"
+#include "select_kernel.h"
+#include "sim_kernel.h"
+#include "vote_kernel.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_CHECK(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(MI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
+
+// --------------------------------------------------------------------------- small kernels
+// pack: float32 source -> compute dtype, K-contiguous rows, zero padded to ld_dst.
+template <typename OutT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src, long long ld_src,
+                                                   long long rows, int D, OutT *__restrict__ dst,
+                                                   long long ld_dst)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const long long r0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    if constexpr (!TRANSPOSED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long r = r0 + ty + i * 8;
+            const int c = c0 + tx;
+            if (r < rows && c < ld_dst) dst[r * ld_dst + c] = (OutT)(c < D ? src[r * ld_src + c] : 0.f);
+        }
+    } else {
+        // src[c][r]: read with r contiguous, write with c contiguous
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + i * 8;
+            const long long r = r0 + tx;
+            tile[ty + i * 8][tx] = (c < D && r < rows) ? src[(long long)c * ld_src + r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long r = r0 + ty + i * 8;
+            const int c = c0 + tx;
+            if (r < rows && c < ld_dst) dst[r * ld_dst + c] = (OutT)tile[tx][ty + i * 8];
+        }
+    }
+}
+
+__global__ void init_state_kernel(float *tau, unsigned *cnt, int *topk_n, int B, int B_pad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B_pad) {
+        tau[i] = i < B ? -INFINITY : INFINITY;
+        cnt[i] = 0u;
+        topk_n[i] = 0;
+    }
+}
+
+// ring-buffer enqueue body: copy `bytes` (16-byte vector path when aligned)
+__global__ void push_kernel(char *__restrict__ dst, const char *__restrict__ src, long long bytes, int vec)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const long long n = bytes >> 4;
+        for (; i < n; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    } else {
+        for (; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
+
+// StorageBank.scatter body: bank[index[i]] = value[i] (rows of row_bytes); out-of-range indices are skipped
+__global__ void scatter_rows_kernel(char *__restrict__ bank, long long K, long long row_bytes,
+                                    const long long *__restrict__ index, const char *__restrict__ value,
+                                    long long b, int vec)
+{
+    const long long per = vec ? row_bytes >> 4 : row_bytes;
+    const long long total = b * per;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i / per, c = i - r * per;
+        long long dst = index[r];
+        if (dst < 0) dst += K;                       // torch-style negative index
+        if (dst < 0 || dst >= K) continue;
+        if (vec) ((uint4 *)(bank + dst * row_bytes))[c] = ((const uint4 *)(value + r * row_bytes))[c];
+        else bank[dst * row_bytes + c] = value[r * row_bytes + c];
+    }
+}
+
+// MoCo forward, step 2: fold the per-strip (max, sumexp) partials and the positive logit.
+__global__ __launch_bounds__(64) void moco_combine_kernel(const float *q, const float *key, int D,
+                                                          const float2 *part, int nparts, int lse_ld,
+                                                          float inv_t, float *lse, float *lpos,
+                                                          float *row_loss)
+{
+    const int row = blockIdx.x, lane = threadIdx.x;
+    float d = 0.f;
+    for (int c = lane; c < D; c += 64) d = fmaf(q[(long long)row * D + c], key[(long long)row * D + c], d);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) d += __shfl_xor(d, s, 64);
+    const float lp = d * inv_t;
+    float m = lp;
+    for (int i = lane; i < nparts; i += 64) m = fmaxf(m, part[(long long)row * lse_ld + i].x);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    float sum = 0.f;
+    for (int i = lane; i < nparts; i += 64) {
+        const float2 ps = part[(long long)row * lse_ld + i];
+        if (ps.y > 0.f) sum += ps.y * expf(ps.x - m);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s, 64);
+    sum += expf(lp - m);
+    if (lane == 0) {
+        const float l = m + logf(sum);
+        lse[row] = l;
+        lpos[row] = d;
+        row_loss[row] = l - lp;
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float *x, int n, float *out)
+{
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0] / (float)n;
+}
+
+// --------------------------------------------------------------------------- top-k plan
+struct Plan {
+    int B_pad, qtiles, pq;
+    int s0_cols;        // dense bootstrap stage
+    int pn_stage;       // bank-tile patches per filter stage
+    int stage_cols;     // bank rows per filter stage
+    int cap;            // candidate slots per row (>= every stage's columns: overflow impossible)
+    size_t off_tau, off_cnt, off_topkn, off_topk, off_cand, total;
+};
+
+constexpr int S0_COLS = 2048;
+
+Plan make_plan(int64_t B, int64_t N, int k)
+{
+    Plan pl{};
+    pl.B_pad = (int)round_up(B, mi::TILE);
+    pl.qtiles = pl.B_pad / mi::TILE;
+    pl.pq = (int)ceil_div(pl.qtiles, mi::PATCH_Q);
+    pl.s0_cols = (int)(N < S0_COLS ? N : S0_COLS);
+    // Filter stage: enough patches for >= 3 rounds on every XCD, a multiple of 8 patches so the
+    // 8 XCDs finish together, and never more columns than remain.
+    const int step = 8 / gcd(pl.pq, 8);
+    int pn = (int)round_up(ceil_div(24, pl.pq), step);
+    const int64_t remaining = N - pl.s0_cols;
+    const int64_t need = ceil_div(remaining > 0 ? remaining : 1, (int64_t)mi::PATCH_N * mi::TILE);
+    if (pn > need) pn = (int)need;
+    if (pn < 1) pn = 1;
+    pl.pn_stage = pn;
+    pl.stage_cols = pn * mi::PATCH_N * mi::TILE;
+    pl.cap = pl.stage_cols > S0_COLS ? pl.stage_cols : S0_COLS;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (size_t)round_up((int64_t)(off + bytes), 256); return o; };
+    pl.off_tau = take((size_t)pl.B_pad * 4);
+    pl.off_cnt = take((size_t)pl.B_pad * 4);
+    pl.off_topkn = take((size_t)pl.B_pad * 4);
+    pl.off_topk = take((size_t)pl.B_pad * k * 8);
+    pl.off_cand = take((size_t)pl.B_pad * pl.cap * 8);
+    pl.total = off;
+    return pl;
+}
+
+template <int DT, int MODE>
+hipError_t launch_sim(const mi::SimParams &p, hipStream_t s)
+{
+    const int patches = p.pq * p.pn;
+    const int grid = (int)ceil_div(patches, 8) * 256;
+    hipLaunchKernelGGL((mi::sim_kernel<DT, MODE>), dim3(grid), dim3(mi::SIM_THREADS), 0, s, p);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_sim_dt(int dtype, const mi::SimParams &p, hipStream_t s)
+{
+    return dtype == MI_BF16 ? launch_sim<mi::DT_BF16, MODE>(p, s) : launch_sim<mi::DT_F32, MODE>(p, s);
+}
+
+int elt_bytes(int dtype) { return dtype == MI_BF16 ? 2 : 4; }
+
+}  // namespace
+
+// =========================================================================== C ABI
+extern "C" {
+
+int mi_abi_version(void) { return MI_ABI_VERSION; }
+const char *mi_last_error(void) { return g_err; }
+
+int64_t mi_knn_ld(int64_t D, int dtype)
+{
+    const int per = mi::KSTEP_BYTES / elt_bytes(dtype);
+    return round_up(D, per);
+}
+
+int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows, int64_t D,
+                 int dtype, void *dst, int64_t ld_dst, mi_stream_t stream)
+{
+    if (!src || !dst || rows <= 0 || D <= 0) return fail(MI_ERR_ARG, "mi_pack_rows: null pointer or empty shape");
+    if (dtype != MI_F32 && dtype != MI_BF16) return fail(MI_ERR_ARG, "mi_pack_rows: bad dtype %d", dtype);
+    if (ld_dst < D || ld_src < (transposed ? rows : D)) return fail(MI_ERR_ARG, "mi_pack_rows: leading dimension too small");
+    if (D > INT32_MAX / 2 || ld_dst > INT32_MAX / 2) return fail(MI_ERR_ARG, "mi_pack_rows: D too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows > (int64_t)INT32_MAX * 16 || ld_dst > 65535 * 32) return fail(MI_ERR_ARG, "mi_pack_rows: shape too large");
+    dim3 grid((unsigned)ceil_div(rows, 32), (unsigned)ceil_div(ld_dst, 32));
+    if (dtype == MI_BF16) {
+        if (transposed) hipLaunchKernelGGL((pack_kernel<__bf16, true>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (__bf16 *)dst, ld_dst);
+        else hipLaunchKernelGGL((pack_kernel<__bf16, false>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (__bf16 *)dst, ld_dst);
+    } else {
+        if (transposed) hipLaunchKernelGGL((pack_kernel<float, true>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (float *)dst, ld_dst);
+        else hipLaunchKernelGGL((pack_kernel<float, false>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (float *)dst, ld_dst);
+    }
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k)
+{
+    if (B <= 0 || N <= 0 || k <= 0 || k > MI_MAX_K || B > (1 << 30) || N > INT32_MAX - 2 * mi::TILE) return 0;
+    return make_plan(B, N, k).total;
+}
+
+int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
+                int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
+                float *out_val, int64_t *out_idx,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream)
+{
+    if (!q || !bank || !out_val || !out_idx || !workspace) return fail(MI_ERR_ARG, "mi_knn_topk: null pointer");
+    if (dtype != MI_F32 && dtype != MI_BF16) return fail(MI_ERR_ARG, "mi_knn_topk: bad dtype %d", dtype);
+    if (B <= 0 || N <= 0 || D <= 0) return fail(MI_ERR_ARG, "mi_knn_topk: empty shape B=%lld N=%lld D=%lld", (long long)B, (long long)N, (long long)D);
+    if (B > (1 << 30) || N > INT32_MAX - 2 * mi::TILE) return fail(MI_ERR_UNSUPPORTED, "mi_knn_topk: B or N too large for one shard");
+    if (k < 1 || k > MI_MAX_K) return fail(MI_ERR_UNSUPPORTED, "mi_knn_topk: k=%d outside [1, %d]", k, MI_MAX_K);
+    if (k > N) return fail(MI_ERR_ARG, "mi_knn_topk: selected index k out of range (k=%d > N=%lld)", k, (long long)N);
+    const int64_t ld = mi_knn_ld(D, dtype);
+    if (ldq != ld || ldb != ld) return fail(MI_ERR_ARG, "mi_knn_topk: ldq/ldb must equal mi_knn_ld(D)=%lld (got %lld, %lld)", (long long)ld, (long long)ldq, (long long)ldb);
+    if (((uintptr_t)q | (uintptr_t)bank | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_knn_topk: q, bank and workspace must be 16-byte aligned");
+    const Plan pl = make_plan(B, N, k);
+    if (workspace_bytes < pl.total) return fail(MI_ERR_WORKSPACE, "mi_knn_topk: workspace %zu < required %zu", workspace_bytes, pl.total);
+
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *tau = (float *)(ws + pl.off_tau);
+    unsigned *cnt = (unsigned *)(ws + pl.off_cnt);
+    int *topk_n = (int *)(ws + pl.off_topkn);
+    unsigned long long *topk = (unsigned long long *)(ws + pl.off_topk);
+    uint2 *cand = (uint2 *)(ws + pl.off_cand);
+
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, cnt, topk_n, (int)B, pl.B_pad);
+    HIP_CHECK(hipGetLastError());
+
+    mi::SimParams sp{};
+    sp.q = (const char *)q;
+    sp.x = (const char *)bank;
+    sp.ldq_bytes = ldq * elt_bytes(dtype);
+    sp.ldx_bytes = ldb * elt_bytes(dtype);
+    sp.B = (int)B;
+    sp.N = (int)N;
+    sp.ksteps = (int)(ld * elt_bytes(dtype) / mi::KSTEP_BYTES);
+    sp.qtiles = pl.qtiles;
+    sp.pq = pl.pq;
+    sp.tau = tau;
+    sp.cnt = cnt;
+    sp.cand = cand;
+    sp.cap = pl.cap;
+
+    mi::SelectParams sel{};
+    sel.cand = cand;
+    sel.cnt = cnt;
+    sel.cap = pl.cap;
+    sel.B = B;
+    sel.topk = topk;
+    sel.topk_n = topk_n;
+    sel.tau = tau;
+    sel.k = k;
+    sel.idx_base = idx_base;
+
+    // stage 0: dense bootstrap over the first s0 bank rows
+    sp.col0 = 0;
+    sp.ncols = pl.s0_cols;
+    sp.ntiles = (int)ceil_div(pl.s0_cols, mi::TILE);
+    sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
+    HIP_CHECK((launch_sim_dt<mi::MODE_DENSE>(dtype, sp, s)));
+    int64_t col = pl.s0_cols;
+    sel.dense_n = pl.s0_cols;
+    sel.dense_col0 = 0;
+    if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
+    hipLaunchKernelGGL((mi::select_kernel<mi::SRC_DENSE>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
+    HIP_CHECK(hipGetLastError());
+
+    // filter stages
+    while (col < N) {
+        const int64_t ncols = (N - col) < pl.stage_cols ? (N - col) : pl.stage_cols;
+        sp.col0 = (int)col;
+        sp.ncols = (int)ncols;
+        sp.ntiles = (int)ceil_div(ncols, mi::TILE);
+        sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
+        HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
+        col += ncols;
+        if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
+        hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
+        HIP_CHECK(hipGetLastError());
+    }
+    return MI_OK;
+}
+
+int mi_knn_merge(const float *cand_val, const int64_t *cand_idx, int G, int64_t B, int kc, int k,
+                 float *out_val, int64_t *out_idx, mi_stream_t stream)
+{
+    if (!cand_val || !cand_idx || !out_val || !out_idx) return fail(MI_ERR_ARG, "mi_knn_merge: null pointer");
+    if (G < 1 || B < 1 || kc < 1 || k < 1 || k > MI_MAX_K) return fail(MI_ERR_ARG, "mi_knn_merge: bad shape G=%d B=%lld kc=%d k=%d", G, (long long)B, kc, k);
+    if ((int64_t)G * kc > 16384) return fail(MI_ERR_UNSUPPORTED, "mi_knn_merge: G*kc=%lld > 16384", (long long)G * kc);
+    if (k > (int64_t)G * kc) return fail(MI_ERR_ARG, "mi_knn_merge: k=%d exceeds the %lld candidates per row", k, (long long)G * kc);
+    mi::SelectParams sel{};
+    sel.g_val = cand_val;
+    sel.g_idx = (const long long *)cand_idx;
+    sel.G = G;
+    sel.kc = kc;
+    sel.B = B;
+    sel.k = k;
+    sel.out_val = out_val;
+    sel.out_idx = (long long *)out_idx;
+    hipLaunchKernelGGL((mi::select_kernel<mi::SRC_GATHER>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, (hipStream_t)stream, sel);
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_knn_vote(const float *val, const int64_t *idx, const int64_t *labels, int64_t n_labels,
+                int64_t B, int k, int classes, float knn_t,
+                float *out_scores, int64_t *out_rank, mi_stream_t stream)
+{
+    if (!val || !idx || !labels || !out_rank) return fail(MI_ERR_ARG, "mi_knn_vote: null pointer");
+    if (B < 1 || n_labels < 1) return fail(MI_ERR_ARG, "mi_knn_vote: empty shape");
+    if (k < 1 || k > MI_MAX_K) return fail(MI_ERR_UNSUPPORTED, "mi_knn_vote: k=%d outside [1, %d]", k, MI_MAX_K);
+    if (classes < 1 || classes > MI_MAX_CLASSES) return fail(MI_ERR_UNSUPPORTED, "mi_knn_vote: classes=%d outside [1, %d]", classes, MI_MAX_CLASSES);
+    if (!(knn_t > 0.f)) return fail(MI_ERR_ARG, "mi_knn_vote: temperature must be positive");
+    mi::VoteParams vp{val, (const long long *)idx, (const long long *)labels, n_labels, k, classes, knn_t, out_scores, (long long *)out_rank};
+    const size_t dyn = (size_t)round_up((int64_t)classes * 2, 16);
+    if (dyn > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void *)mi::vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(mi::vote_kernel, dim3((unsigned)B), dim3(mi::VOTE_THREADS), dyn, (hipStream_t)stream, vp);
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_queue_push(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
+                  const void *value, int64_t b, int64_t *new_ptr, mi_stream_t stream)
+{
+    if (!queue || !value) return fail(MI_ERR_ARG, "mi_queue_push: null pointer");
+    if (K < 1 || row_bytes < 1 || b < 0 || ptr < 0 || ptr >= K) return fail(MI_ERR_ARG, "mi_queue_push: bad shape K=%lld row_bytes=%lld b=%lld ptr=%lld", (long long)K, (long long)row_bytes, (long long)b, (long long)ptr);
+    const int64_t w = b < K - ptr ? b : K - ptr;       // truncate: overflow rows are dropped (memory_bank.py:68-70)
+    if (w > 0) {
+        char *dst = (char *)queue + ptr * row_bytes;
+        const long long bytes = w * row_bytes;
+        const int vec = ((((uintptr_t)dst | (uintptr_t)value) & 15) == 0 && (bytes & 15) == 0) ? 1 : 0;
+        const long long items = vec ? bytes >> 4 : bytes;
+        int grid = (int)ceil_div(items, 256);
+        if (grid > 2048) grid = 2048;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(push_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, (const char *)value, bytes, vec);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (new_ptr) *new_ptr = (ptr + w) % K;
+    return MI_OK;
+}
+
+int mi_bank_scatter(void *bank, int64_t K, int64_t row_bytes, const int64_t *index,
+                    const void *value, int64_t b, mi_stream_t stream)
+{
+    if (!bank || !index || !value) return fail(MI_ERR_ARG, "mi_bank_scatter: null pointer");
+    if (K < 1 || row_bytes < 1 || b < 0) return fail(MI_ERR_ARG, "mi_bank_scatter: bad shape");
+    if (b == 0) return MI_OK;
+    const int vec = ((((uintptr_t)bank | (uintptr_t)value) & 15) == 0 && (row_bytes & 15) == 0) ? 1 : 0;
+    const long long items = b * (vec ? row_bytes >> 4 : row_bytes);
+    int grid = (int)ceil_div(items, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (char *)bank, (long long)K,
+                       (long long)row_bytes, (const long long *)index, (const char *)value, (long long)b, vec);
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ MoCo queue logits
+namespace {
+struct MocoPlan { int b_pad, ntiles, lse_ld; size_t off_part, off_rowloss, total; };
+MocoPlan moco_plan(int64_t b, int64_t K)
+{
+    MocoPlan m{};
+    m.b_pad = (int)round_up(b, mi::TILE);
+    m.ntiles = (int)ceil_div(K, mi::TILE);
+    m.lse_ld = m.ntiles * 4;
+    m.off_part = 0;
+    m.off_rowloss = (size_t)round_up((int64_t)m.b_pad * m.lse_ld * 8, 256);
+    m.total = m.off_rowloss + (size_t)round_up((int64_t)m.b_pad * 4, 256);
+    return m;
+}
+}  // namespace
+
+size_t mi_moco_workspace_bytes(int64_t b, int64_t K, int64_t D)
+{
+    if (b <= 0 || K <= 0 || D <= 0) return 0;
+    return moco_plan(b, K).total;
+}
+
+int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
+                int64_t D, float temperature, float *lse, float *lpos, float *loss,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream)
+{
+    if (!q || !key || !queue || !lse || !lpos || !loss || !workspace) return fail(MI_ERR_ARG, "mi_moco_fwd: null pointer");
+    if (b < 1 || K < 1 || D < 1 || b > (1 << 24) || K > INT32_MAX - 2 * mi::TILE) return fail(MI_ERR_ARG, "mi_moco_fwd: bad shape");
+    if (D % 32) return fail(MI_ERR_UNSUPPORTED, "mi_moco_fwd: D=%lld must be a multiple of 32", (long long)D);
+    if (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_moco_fwd: q, queue, workspace must be 16-byte aligned");
+    if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_moco_fwd: temperature must be positive");
+    const MocoPlan mp = moco_plan(b, K);
+    if (workspace_bytes < mp.total) return fail(MI_ERR_WORKSPACE, "mi_moco_fwd: workspace %zu < required %zu", workspace_bytes, mp.total);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    mi::SimParams sp{};
+    sp.q = (const char *)q;
+    sp.x = (const char *)queue;
+    sp.ldq_bytes = sp.ldx_bytes = D * 4;
+    sp.B = (int)b;
+    sp.N = (int)K;
+    sp.ksteps = (int)(D * 4 / mi::KSTEP_BYTES);
+    sp.col0 = 0;
+    sp.ncols = (int)K;
+    sp.qtiles = mp.b_pad / mi::TILE;
+    sp.ntiles = mp.ntiles;
+    sp.pq = (int)ceil_div(sp.qtiles, mi::PATCH_Q);
+    sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
+    sp.inv_t = 1.0f / temperature;
+    sp.lse_part = (float2 *)(ws + mp.off_part);
+    sp.lse_ld = mp.lse_ld;
+    HIP_CHECK((launch_sim<mi::DT_F32, mi::MODE_LSE>(sp, s)));
+    float *row_loss = (float *)(ws + mp.off_rowloss);
+    hipLaunchKernelGGL(moco_combine_kernel, dim3((unsigned)b), dim3(64), 0, s, q, key, (int)D, sp.lse_part, mp.lse_ld, mp.lse_ld, sp.inv_t, lse, lpos, row_loss);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)b, loss);
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
+                int64_t D, float temperature, const float *lse, const float *lpos,
+                const float *grad_loss, float *dq,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream)
+{
+    (void)q; (void)key; (void)queue; (void)b; (void)K; (void)D; (void)temperature; (void)lse; (void)lpos;
+    (void)grad_loss; (void)dq; (void)workspace; (void)workspace_bytes; (void)stream;
+    return fail(MI_ERR_UNSUPPORTED, "mi_moco_bwd: not built yet");
+}
+
+}  // extern "C"

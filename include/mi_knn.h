@@ -1,0 +1,125 @@
+/* mi_knn.h -- C ABI of the MI355X (gfx950) feature-bank similarity library (libmi_knn.so).
+ *
+ * Drop-in boundary for ONE path of sailist/image-classification: the weighted-kNN monitor
+ * (models/knn.py) and the MoCo queue (models/memory_bank.py, track_ssl/moco.py).  The reference
+ * is pure Python on torch; it has no FFI of its own.  What a maintainer binds from Python is
+ * shown in INTEGRATION.md (ctypes, as `image-classification_amd/_lib.py` does).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless it says "host";
+ *   - plain pointers and sizes only, no torch types; the library never allocates or frees
+ *     caller memory: outputs and workspaces are caller-allocated (sizes from the *_bytes calls);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, nothing synchronises the host;
+ *   - every entry point returns 0 (MI_OK) or a negative MI_ERR_* code; the message of the last
+ *     error on the calling thread is available from mi_last_error();
+ *   - re-entrant: no global mutable state except that thread-local error string.
+ */
+#ifndef MI_KNN_H
+#define MI_KNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
+enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
+enum { MI_MAX_K = 1024, MI_MAX_CLASSES = 65536 };
+
+typedef void *mi_stream_t;
+
+int mi_abi_version(void);
+const char *mi_last_error(void);
+
+/* Leading dimension (in ELEMENTS of `dtype`) the similarity kernels require for a D-wide row:
+ * D rounded up so that a row is a whole number of 128-byte K-steps (32 f32 / 64 bf16). */
+int64_t mi_knn_ld(int64_t D, int dtype);
+
+/* Pack float32 rows into the compute layout: dst[r][0..D) = (dtype) src(r, .), dst[r][D..ld_dst) = 0.
+ * transposed == 0: src is [rows, D] with leading dimension ld_src  (query matrix; [N, D] bank).
+ * transposed == 1: src is [D, rows] with leading dimension ld_src  (the reference's bank layout:
+ *                  track_ssl/ssltrainer.py:179 hands knn_predict a physically transposed [D, N]).
+ * Replaces: the layout/dtype handling torch.mm does implicitly at models/knn.py:6. */
+int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows, int64_t D,
+                 int dtype, void *dst, int64_t ld_dst, mi_stream_t stream);
+
+/* Workspace (bytes) for mi_knn_topk. */
+size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k);
+
+/* Fused similarity GEMM + streaming per-row top-k.  Replaces models/knn.py:6 (torch.mm) and
+ * models/knn.py:8 (topk) without materialising the [B, N] similarity matrix.
+ *   q    [B, ldq]  packed queries  (dtype, K-contiguous, ldq == mi_knn_ld(D, dtype), 16-B aligned)
+ *   bank [N, ldb]  packed bank rows (same dtype; one row per bank entry = a row shard of the bank)
+ *   out_val [B, k] float32 similarities, sorted descending; ties -> lower bank index first
+ *   out_idx [B, k] int64 = idx_base + local bank row (idx_base = first global row of this shard)
+ * Rows with fewer than k finite similarities are padded with (-inf, -1).  NaN similarities are
+ * never selected.  Requires 1 <= k <= min(N, MI_MAX_K).
+ * fp32 mode accumulates each dot product as ONE k-ascending fused-multiply-add chain (bit-exact
+ * against oracle/knn_chain.c); bf16 mode uses bf16 MFMA with float32 accumulation. */
+int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
+                int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
+                float *out_val, int64_t *out_idx,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* Deterministic merge of per-shard candidates (the step after the RCCL all-gather; no reference
+ * counterpart -- the reference kNN is single-device).
+ *   cand_val [G, B, kc] float32, cand_idx [G, B, kc] int64 (global rows; < 0 = padding)
+ *   -> out_val/out_idx [B, k], total order (value desc, global index asc).  G*kc <= 16384,
+ *      every valid index < 2^32. */
+int mi_knn_merge(const float *cand_val, const int64_t *cand_idx, int G, int64_t B, int kc, int k,
+                 float *out_val, int64_t *out_idx, mi_stream_t stream);
+
+/* Label gather + exp(s/T) weights + per-class vote + full class ranking.
+ * Replaces models/knn.py:10-20 (gather, div/exp, one-hot scatter, weighted sum, argsort).
+ *   val/idx     [B, k] from mi_knn_topk / mi_knn_merge (idx < 0 entries are skipped)
+ *   labels      [n_labels] int64 class ids of the bank rows that idx addresses
+ *   out_scores  [B, classes] float32 or NULL
+ *   out_rank    [B, classes] int64: classes by score descending, ties -> lower class id
+ * Votes of one class are summed over neighbours in ascending neighbour rank (deterministic).
+ * 1 <= classes <= MI_MAX_CLASSES, 1 <= k <= MI_MAX_K. */
+int mi_knn_vote(const float *val, const int64_t *idx, const int64_t *labels, int64_t n_labels,
+                int64_t B, int k, int classes, float knn_t,
+                float *out_scores, int64_t *out_rank, mi_stream_t stream);
+
+/* Truncating ring-buffer enqueue.  Replaces models/memory_bank.py:65-72 (MemoryBank.push):
+ * writes w = min(b, K - ptr) rows of `value` at queue[ptr .. ptr+w) and stores the new pointer
+ * (ptr + w) % K to *new_ptr (HOST pointer, may be NULL).  Overflow rows are dropped, exactly as
+ * the reference does.  row_bytes = bytes of one queue row (any dtype). */
+int mi_queue_push(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
+                  const void *value, int64_t b, int64_t *new_ptr, mi_stream_t stream);
+
+/* Index-addressed row store.  Replaces models/memory_bank.py:32 (StorageBank.scatter:
+ * `self[name][index] = value`): bank[index[i]] = value[i] for i < b; rows of row_bytes bytes.
+ * Negative indices count from the end (torch semantics); out-of-range indices are skipped. */
+int mi_bank_scatter(void *bank, int64_t K, int64_t row_bytes, const int64_t *index,
+                    const void *value, int64_t b, mi_stream_t stream);
+
+/* MoCo InfoNCE over a negative queue, forward.  Replaces the arithmetic behind
+ * track_ssl/moco.py:152-156 (lumo contrastive_loss2 with query_neg=False, key_neg=False,
+ * norm=False; third-party source absent: parity unpinned, MoCo-paper form):
+ *   l_pos[i] = q_i . key_i ; l_neg = q @ queue^T ; logits = [l_pos, l_neg] / T
+ *   lse[i] = logsumexp(logits_i) ; loss = mean_i(lse[i] - l_pos[i] / T)
+ * q, key [b, D] float32 (leading dim D), queue [K, D] float32, D % 32 == 0.
+ * Outputs: lse [b], lpos [b], loss [1] (all device float32).  The logits are never written. */
+size_t mi_moco_workspace_bytes(int64_t b, int64_t K, int64_t D);
+int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
+                int64_t D, float temperature, float *lse, float *lpos, float *loss,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* Backward w.r.t. the query only (key and queue are detached at the call site):
+ *   dq[i] = grad_loss / (b T) * ( sum_n softmax_i[n] queue[n] + (softmax_i[pos] - 1) key_i )
+ * grad_loss: device pointer to the upstream scalar gradient. */
+int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
+                int64_t D, float temperature, const float *lse, const float *lpos,
+                const float *grad_loss, float *dq,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_KNN_H */

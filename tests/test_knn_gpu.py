@@ -1,0 +1,242 @@
+"""GPU parity tests (run on the MI355X box: ``pytest -m gpu``).  Everything goes through the C ABI
+(``libmi_knn.so``) via the package's ctypes binding; the oracle is only the checker."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain
+from oracle import knn_oracle as ko
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ica():
+    import image_classification_amd as pkg
+    pkg._lib.lib()                       # fail loudly if the HIP library is missing
+    return pkg
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def run_full(ica, feature, bank_rows, labels, C, k, T, compute_dtype, layout="reference"):
+    f = dev(feature)
+    if layout == "reference":
+        bank = dev(np.ascontiguousarray(bank_rows.T))                      # [D, N] like ssltrainer.py:179
+    elif layout == "view":
+        bank = dev(bank_rows).t()                                          # transposed view of [N, D]
+    else:
+        bank = ica.BankIndex.from_rows(dev(bank_rows), compute_dtype)
+    out = ica.knn_predict_full(f, bank, dev(labels), C, k, T, compute_dtype=compute_dtype)
+    torch.cuda.synchronize()
+    return {n: v.cpu().numpy() for n, v in out.items()}
+
+
+# ----------------------------------------------------------------------------- fp32: bit-exact vs the chain oracle
+@pytest.mark.parametrize("name", P.KNN_CASES)
+@pytest.mark.parametrize("layout", ["reference", "rows"])
+def test_fp32_bit_exact_vs_chain_oracle(ica, name, layout):
+    z = P.load_case(name)
+    sim = chain.sim_chain_f32(z["feature"], z["bank_rows"])
+    ref = ko.knn_from_similarity(sim, z["labels"], z["classes"], z["knn_k"], z["knn_t"])
+    out = run_full(ica, z["feature"], z["bank_rows"], z["labels"], z["classes"], z["knn_k"], z["knn_t"], "fp32", layout)
+    # integer / index work and the fp32 similarities: bit-exact
+    assert np.array_equal(out["sim_weight"], ref["sim_weight"]), \
+        f"{name}: similarities differ, max |d| = {np.max(np.abs(out['sim_weight'] - ref['sim_weight']))}"
+    assert np.array_equal(out["sim_indices"], ref["sim_indices"]), f"{name}: top-k indices differ"
+    # floating point vote: 1e-5 relative (expf implementations differ in the last ulp)
+    P.check_scores(out["pred_scores"], ref["pred_scores"], name)
+    P.check_ranking_prefix(out["pred_labels"], out["pred_scores"], name)
+    P.check_top1(out["pred_labels"], ref["pred_labels"], ref["pred_scores"], name)
+    assert out["pred_labels"].dtype == np.int64 and out["pred_labels"].shape == (z["feature"].shape[0], z["classes"])
+
+
+@pytest.mark.parametrize("name", P.KNN_CASES)
+def test_fp32_vs_reference_golden(ica, name):
+    """Against the REFERENCE's own outputs (torch.mm / topk / vote), SURVEY 8(c) contract."""
+    z = P.load_case(name)
+    D = z["feature"].shape[1]
+    exact = name in P.EXACT_CASES
+    out = run_full(ica, z["feature"], z["bank_rows"], z["labels"], z["classes"], z["knn_k"], z["knn_t"], "fp32")
+    P.check_topk(out["sim_weight"], out["sim_indices"], z["sim_weight"], z["sim_indices"], z["kth_gap"], D, exact, name)
+    P.check_lower_index_ties(out["sim_weight"], out["sim_indices"], name)
+    rows = P.decided_rows(z["kth_gap"], D, exact)
+    P.check_scores(out["pred_scores"], z["pred_scores"], name, rows=rows)
+    P.check_top1(out["pred_labels"], z["pred_labels"], z["pred_scores"], name, rows=rows)
+
+
+def test_knn_predict_signature_and_view_layout(ica):
+    z = P.load_case("knn_rand_cifar100")
+    f, lab = dev(z["feature"]), dev(z["labels"])
+    a = ica.knn_predict(f, dev(np.ascontiguousarray(z["bank_rows"].T)), lab, z["classes"], z["knn_k"], z["knn_t"])
+    b = ica.knn_predict(f, dev(z["bank_rows"]).t(), lab, z["classes"], z["knn_k"], z["knn_t"])   # zero-copy view
+    assert a.dtype == torch.int64 and tuple(a.shape) == (f.shape[0], z["classes"]) and a.is_cuda
+    assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------- bf16 mode
+@pytest.mark.parametrize("name", ["knn_bf16_inputs", "knn_rand_cifar100", "knn_clustered", "knn_rand_ragged"])
+def test_bf16_vs_bf16_oracle(ica, name):
+    """Oracle for bf16 mode = reference arithmetic on bf16-rounded inputs.  The MFMA's
+    internal add order is hardware defined, so values get a tolerance and index sets are compared
+    where the k-th gap exceeds it."""
+    z = P.load_case(name)
+    D = z["feature"].shape[1]
+    qb, xb = ko.to_bf16_bits(z["feature"]), ko.to_bf16_bits(z["bank_rows"])
+    sim = chain.sim_bf16_f64(qb, xb)
+    k = z["knn_k"]
+    ref = ko.knn_from_similarity(sim, z["labels"], z["classes"], k, z["knn_t"])
+    srt = -np.sort(-sim, axis=1)
+    gap = srt[:, k - 1] - srt[:, k] if k < sim.shape[1] else np.full(sim.shape[0], np.inf, np.float32)
+    out = run_full(ica, z["feature"], z["bank_rows"], z["labels"], z["classes"], k, z["knn_t"], "bf16")
+    n = P.check_topk(out["sim_weight"], out["sim_indices"], ref["sim_weight"], ref["sim_indices"], gap, D, False, name)
+    assert n > 0
+    rows = P.decided_rows(gap, D)
+    # bf16 similarities differ from the float64-accumulated oracle by float32 rounding only;
+    # exp(s/T) amplifies that by 1/T: tolerance 1e-5 + D*eps/T relative
+    rtol = 1e-5 + P.val_atol(D) / z["knn_t"]
+    P.check_scores(out["pred_scores"], ref["pred_scores"], name, rtol=rtol, rows=rows)
+    P.check_top1(out["pred_labels"], ref["pred_labels"], ref["pred_scores"], name, rtol=rtol, rows=rows)
+
+
+@pytest.mark.parametrize("name", P.EXACT_CASES)
+def test_bf16_exact_arithmetic_cases_bit_exact(ica, name):
+    """Dyadic-grid inputs are bf16-representable and every add order is exact: bf16 == fp32 == oracle."""
+    z = P.load_case(name)
+    sim = chain.sim_chain_f32(z["feature"], z["bank_rows"])
+    ref = ko.knn_from_similarity(sim, z["labels"], z["classes"], z["knn_k"], z["knn_t"])
+    out = run_full(ica, z["feature"], z["bank_rows"], z["labels"], z["classes"], z["knn_k"], z["knn_t"], "bf16", "rows")
+    assert np.array_equal(out["sim_weight"], ref["sim_weight"])
+    assert np.array_equal(out["sim_indices"], ref["sim_indices"])
+
+
+# ----------------------------------------------------------------------------- multi-stage / adversarial / edge cases
+def _rand_case(B, N, D, C, seed):
+    rs = np.random.RandomState(seed)
+    return ko.l2_normalize(rs.randn(B, D)), ko.l2_normalize(rs.randn(N, D)), rs.randint(0, C, size=N)
+
+
+@pytest.mark.parametrize("B,N,D,k", [(300, 60000, 64, 200), (1, 5000, 32, 7), (513, 2049, 96, 200), (40, 30000, 160, 1024)])
+def test_fp32_multi_stage_bit_exact(ica, B, N, D, k):
+    f, x, lab = _rand_case(B, N, D, 10, B + N)
+    sim = chain.sim_chain_f32(f, x)
+    v_ref, i_ref = chain.topk_rows(sim, k)
+    v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), k)
+    assert np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+
+
+def test_adversarial_ascending_similarity(ica):
+    """Every later bank row beats every earlier one: all elements pass the stale threshold, the
+    candidate lists fill to their worst case and must not overflow."""
+    rs = np.random.RandomState(7)
+    D, N, B, k = 32, 30000, 9, 50
+    u = ko.l2_normalize(rs.randn(1, D))[0]
+    x = (np.linspace(0.01, 1.0, N, dtype=np.float32)[:, None] * u[None, :]).astype(np.float32)
+    f = np.tile(u, (B, 1)).astype(np.float32) * np.linspace(0.5, 1.0, B, dtype=np.float32)[:, None]
+    sim = chain.sim_chain_f32(f, x)
+    v_ref, i_ref = chain.topk_rows(sim, k)
+    v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), k)
+    assert np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+
+
+def test_all_ties_pick_lowest_indices(ica):
+    D, N, B, k = 32, 7000, 5, 200
+    x = np.tile(np.full((1, D), 0.125, np.float32), (N, 1))
+    f = np.full((B, D), 0.25, np.float32)
+    for dt in ("fp32", "bf16"):
+        v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), dt), k)
+        assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(k), (B, 1)))
+        assert np.all(v.cpu().numpy() == np.float32(D * 0.125 * 0.25))
+
+
+def test_k_larger_than_n_raises_like_torch(ica):
+    f, x, _ = _rand_case(4, 10, 32, 3, 0)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), 11)
+
+
+def test_bad_arguments(ica):
+    f, x, lab = _rand_case(4, 10, 32, 3, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ica.knn_predict(torch.from_numpy(f), torch.from_numpy(x.T.copy()), torch.from_numpy(lab), 3, 2, 0.1)
+    with pytest.raises(ValueError):
+        ica.knn_predict(dev(f), dev(x.T.copy()), dev(lab[:5]), 3, 2, 0.1)
+    with pytest.raises(ValueError):
+        ica.knn_topk(dev(f[:, :16]), ica.BankIndex.from_rows(dev(x), "fp32"), 2)
+    with pytest.raises((ValueError, RuntimeError)):
+        ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(np.tile(x, (300, 1))), "fp32"), 2000)    # k > MI_MAX_K
+
+
+def test_index_base_and_merge_equals_unsharded(ica):
+    """Row-sharded bank: local top-k with global indices, deterministic merge == single-shard result."""
+    f, x, lab = _rand_case(70, 9000, 64, 10, 3)
+    x[4000:4100] = x[100:200]                               # cross-shard exact ties
+    k = 200
+    v_ref, i_ref = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), k)
+    for G in (2, 4, 8):
+        n = x.shape[0] // G
+        vs, is_ = [], []
+        for g in range(G):
+            lo, hi = g * n, (x.shape[0] if g == G - 1 else (g + 1) * n)
+            v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x[lo:hi]), "fp32", idx_base=lo), k)
+            vs.append(v)
+            is_.append(i)
+        v, i = ica.knn_merge(torch.stack(vs), torch.stack(is_), k)
+        assert torch.equal(v, v_ref) and torch.equal(i, i_ref), f"G={G}"
+        vo, io = ko.merge_topk(torch.stack(vs).cpu().numpy(), torch.stack(is_).cpu().numpy(), k)
+        assert np.array_equal(v.cpu().numpy(), vo) and np.array_equal(i.cpu().numpy(), io)
+
+
+@pytest.mark.parametrize("C,k", [(1, 5), (10, 200), (1000, 200), (5000, 64), (65536, 33)])
+def test_vote_kernel_vs_oracle(ica, C, k):
+    rs = np.random.RandomState(C + k)
+    B, N = 37, 5000
+    val = -np.sort(-rs.uniform(-1, 1, size=(B, k)).astype(np.float32), axis=1)
+    idx = np.stack([rs.permutation(N)[:k] for _ in range(B)]).astype(np.int64)
+    lab = rs.randint(0, C, size=N)
+    T = 0.1
+    rank, scores = ica.knn_vote(dev(val), dev(idx), dev(lab), C, T, return_scores=True)
+    w = ko.vote_weights(val, T)
+    s_ref = ko.vote_scores(w, lab[idx], C)
+    P.check_scores(scores.cpu().numpy(), s_ref, f"C={C}")
+    P.check_ranking_prefix(rank.cpu().numpy(), scores.cpu().numpy(), f"C={C}")
+    P.check_top1(rank.cpu().numpy(), ko.rank_classes(s_ref), s_ref, f"C={C}")
+
+
+def test_vote_skips_padding_entries(ica):
+    val = dev(np.array([[0.9, 0.5, -np.inf]], np.float32))
+    idx = dev(np.array([[2, 0, -1]], np.int64))
+    lab = dev(np.array([1, 0, 1], np.int64))
+    rank, scores = ica.knn_vote(val, idx, lab, 3, 0.5, return_scores=True)
+    s = scores.cpu().numpy()[0]
+    assert s[2] == 0 and np.allclose(s[:2], [np.exp(1.0), np.exp(1.8)], rtol=1e-6)
+    assert rank.cpu().numpy()[0].tolist() == [1, 0, 2]
+
+
+def test_deterministic_across_runs(ica):
+    f, x, lab = _rand_case(257, 20000, 128, 100, 11)
+    a = ica.knn_predict_full(dev(f), dev(x.T.copy()), dev(lab), 100, 200, 0.1, compute_dtype="bf16")
+    b = ica.knn_predict_full(dev(f), dev(x.T.copy()), dev(lab), 100, 200, 0.1, compute_dtype="bf16")
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
+
+
+def test_pack_rows(ica):
+    rs = np.random.RandomState(0)
+    x = rs.randn(70, 50).astype(np.float32)
+    for dt, tdt, ld in (("fp32", torch.float32, 64), ("bf16", torch.bfloat16, 64)):
+        p = ica.pack_rows(dev(x), False, dt)
+        pt = ica.pack_rows(dev(np.ascontiguousarray(x.T)), True, dt)
+        assert p.data.shape == (70, ld) and p.data.dtype == tdt
+        ref = torch.zeros(70, ld)
+        ref[:, :50] = torch.from_numpy(x)
+        ref = ref.to(tdt)
+        assert torch.equal(p.data.cpu(), ref) and torch.equal(pt.data.cpu(), ref)
+    y = dev(rs.randn(8, 64).astype(np.float32))
+    assert ica.pack_rows(y, False, "fp32").data.data_ptr() == y.data_ptr()           # zero copy
