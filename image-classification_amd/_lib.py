@@ -15,7 +15,7 @@ MI_MAX_K, MI_MAX_CLASSES = 1024, 65536
 ABI_VERSION = 1
 
 EXPORTS = [
-    "mi_abi_version", "mi_last_error", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes",
+    "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes",
     "mi_knn_topk", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
     "mi_moco_fwd", "mi_moco_bwd",
 ]
@@ -41,6 +41,9 @@ def lib() -> ctypes.CDLL:
     L.mi_abi_version.restype = i32
     L.mi_last_error.restype = ctypes.c_char_p
     L.mi_knn_ld.restype, L.mi_knn_ld.argtypes = i64, [i64, i32]
+    L.mi_profile_enable.restype, L.mi_profile_enable.argtypes = i32, [i32]
+    L.mi_profile_collect.restype = i32
+    L.mi_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
     L.mi_pack_rows.restype = i32
     L.mi_pack_rows.argtypes = [p, i64, i32, i64, i64, i32, p, i64, p]
     L.mi_knn_topk_workspace_bytes.restype = sz
@@ -78,3 +81,14 @@ def check(rc: int, what: str) -> None:
 def stream_ptr(device) -> int:
     import torch
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().mi_profile_enable(1 if on else 0), "mi_profile_enable")
+
+
+def profile_collect(kind: int):
+    """(total_ms, launches, total_work) of the recorded launches of `kind` (0 = similarity, 1 = select)."""
+    ms, n, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+    check(lib().mi_profile_collect(kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work)), "mi_profile_collect")
+    return ms.value, n.value, work.value

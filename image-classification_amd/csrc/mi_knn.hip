@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/mi_knn.h"
 #include "select_kernel.h"
 #include "sim_kernel.h"
@@ -34,6 +37,36 @@ int fail(int code, const char *fmt, ...)
             return fail(MI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                              \
     } while (0)
+
+// ---- optional per-launch timing (bench.py's roofline leg).  Off by default; when on, every
+// similarity-kernel launch is bracketed by HIP events on ITS OWN stream.  Debug facility: guarded
+// by a mutex, not meant for concurrent callers.
+struct ProfRec { hipEvent_t e0, e1; int kind; double work; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    bool on = false;
+    ProfRec r{};
+    hipStream_t s;
+    ProfScope(int kind, double work, hipStream_t stream) : s(stream)
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_on) return;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        r.kind = kind;
+        r.work = work;
+        on = hipEventRecord(r.e0, s) == hipSuccess;
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        hipEventRecord(r.e1, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(r);
+    }
+};
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -228,6 +261,41 @@ extern "C" {
 int mi_abi_version(void) { return MI_ABI_VERSION; }
 const char *mi_last_error(void) { return g_err; }
 
+int mi_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    if (!g_prof_on) {
+        for (auto &r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        g_prof.clear();
+    }
+    return MI_OK;
+}
+
+int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *total_work)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0.0, work = 0.0;
+    int64_t n = 0;
+    std::vector<ProfRec> keep;
+    for (auto &r : g_prof) {
+        if (r.kind != kind) { keep.push_back(r); continue; }
+        float t = 0.f;
+        HIP_CHECK(hipEventSynchronize(r.e1));
+        HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+        ms += t;
+        work += r.work;
+        ++n;
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    g_prof.swap(keep);
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (total_work) *total_work = work;
+    return MI_OK;
+}
+
 int64_t mi_knn_ld(int64_t D, int dtype)
 {
     const int per = mi::KSTEP_BYTES / elt_bytes(dtype);
@@ -320,13 +388,19 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     sp.ncols = pl.s0_cols;
     sp.ntiles = (int)ceil_div(pl.s0_cols, mi::TILE);
     sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
-    HIP_CHECK((launch_sim_dt<mi::MODE_DENSE>(dtype, sp, s)));
+    {
+        ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * sp.ncols * (double)D, s);
+        HIP_CHECK((launch_sim_dt<mi::MODE_DENSE>(dtype, sp, s)));
+    }
     int64_t col = pl.s0_cols;
     sel.dense_n = pl.s0_cols;
     sel.dense_col0 = 0;
     if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
-    hipLaunchKernelGGL((mi::select_kernel<mi::SRC_DENSE>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
-    HIP_CHECK(hipGetLastError());
+    {
+        ProfScope ps(MI_PROF_SELECT, (double)B * sel.dense_n * 4.0, s);
+        hipLaunchKernelGGL((mi::select_kernel<mi::SRC_DENSE>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
+        HIP_CHECK(hipGetLastError());
+    }
 
     // filter stages
     while (col < N) {
@@ -335,11 +409,17 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
         sp.ncols = (int)ncols;
         sp.ntiles = (int)ceil_div(ncols, mi::TILE);
         sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
-        HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
+        {
+            ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)ncols * (double)D, s);
+            HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
+        }
         col += ncols;
         if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
-        hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
-        HIP_CHECK(hipGetLastError());
+        {
+            ProfScope ps(MI_PROF_SELECT, (double)B * k * 16.0, s);
+            hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
+            HIP_CHECK(hipGetLastError());
+        }
     }
     return MI_OK;
 }

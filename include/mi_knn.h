@@ -36,6 +36,16 @@ typedef void *mi_stream_t;
 int mi_abi_version(void);
 const char *mi_last_error(void);
 
+/* Optional per-launch timing for benchmarks (no reference counterpart).  While enabled, every
+ * similarity-kernel launch (kind MI_PROF_SIM; `work` = algorithmic flops 2*B*cols*D of that
+ * launch) and every select launch (MI_PROF_SELECT; work = bytes) is bracketed by HIP events on the
+ * stream it is launched on.  mi_profile_collect waits for the recorded launches of `kind`, returns
+ * their summed duration (ms), count and work, and forgets them.  Process-wide debug state behind
+ * a mutex; leave it off in production. */
+enum { MI_PROF_SIM = 0, MI_PROF_SELECT = 1 };
+int mi_profile_enable(int on);
+int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *total_work);
+
 /* Leading dimension (in ELEMENTS of `dtype`) the similarity kernels require for a D-wide row:
  * D rounded up so that a row is a whole number of 128-byte K-steps (32 f32 / 64 bf16). */
 int64_t mi_knn_ld(int64_t D, int dtype);

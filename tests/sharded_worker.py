@@ -1,0 +1,81 @@
+"""Worker for the multi-process sharded-kNN tests (spawned by test_sharded_*.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import knn_oracle as ko          # noqa: E402
+from oracle import knn_torch_cpu as kt       # noqa: E402
+
+
+class OracleOps:
+    """CPU stand-ins for the HIP primitives (tests only): lets gloo exercise the orchestration."""
+
+    def build_bank(self, rows, idx_base):
+        return rows.float(), int(idx_base)
+
+    def bank_rows(self, bank):
+        return bank[0].shape[0]
+
+    def topk(self, feature, bank, k):
+        v, i = kt.topk_rows(feature, bank[0], k)
+        return v, i + bank[1]
+
+    def merge(self, gv, gi, k):
+        v, i = ko.merge_topk(gv.numpy(), gi.numpy(), k)
+        return torch.from_numpy(v), torch.from_numpy(i)
+
+    def vote(self, val, idx, labels, classes, knn_t):
+        w = ko.vote_weights(val.numpy(), knn_t)
+        s = ko.vote_scores(w, labels.numpy()[idx.numpy()], classes)
+        return torch.from_numpy(ko.rank_classes(s))
+
+
+def make_case(seed=0, B=50, N=1203, D=32, C=7):
+    rs = np.random.RandomState(seed)
+    f = ko.l2_normalize(rs.randn(B, D))
+    x = ko.l2_normalize(rs.randn(N, D))
+    x[700:760] = x[10:70]                      # exact ties across the shard boundary
+    lab = rs.randint(0, C, size=N)
+    return f, x, lab, C
+
+
+def main(rank, world, port, use_gpu, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import image_classification_amd as ica
+        from image_classification_amd import sharded  # noqa: F401  (alias import path)
+        sh = sys.modules["image-classification_amd.sharded"]
+        f, x, lab, C = make_case()
+        k, T = 40, 0.1
+        lo, hi = sh.shard_bounds(x.shape[0], world, rank)
+        dev = torch.device("cuda:0") if use_gpu else torch.device("cpu")
+        ops = None if use_gpu else OracleOps()
+        knn = sh.ShardedKnn(torch.from_numpy(x[lo:hi]).to(dev), lo, ops=ops, compute_dtype="fp32", query_chunk=16)
+        assert knn.n_total == x.shape[0] and knn.shard_sizes[rank] == hi - lo
+        val, idx = knn.topk(torch.from_numpy(f).to(dev), k)
+        pred = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), val=val.cpu().numpy(), idx=idx.cpu().numpy(),
+                 pred=pred.cpu().numpy())
+        # MemoryBank.push all-gathers the keys of every rank first (memory_bank.py:64)
+        if use_gpu:
+            mb = ica.MemoryBank()
+            mb.register("negative", dim=4, k=10)
+            mb = mb.to(dev)
+            mb.push("negative", torch.full((3, 4), float(rank + 1), device=dev))
+            got = mb["negative"][:3 * world, 0].cpu().numpy()
+            assert got.tolist() == [float(r + 1) for r in range(world) for _ in range(3)], got
+            assert mb.offsets["negative"] == 3 * world
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "gpu", sys.argv[5])

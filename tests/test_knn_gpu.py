@@ -212,7 +212,7 @@ def test_vote_kernel_vs_oracle(ica, C, k):
 def test_vote_skips_padding_entries(ica):
     val = dev(np.array([[0.9, 0.5, -np.inf]], np.float32))
     idx = dev(np.array([[2, 0, -1]], np.int64))
-    lab = dev(np.array([1, 0, 1], np.int64))
+    lab = dev(np.array([0, 2, 1], np.int64))
     rank, scores = ica.knn_vote(val, idx, lab, 3, 0.5, return_scores=True)
     s = scores.cpu().numpy()[0]
     assert s[2] == 0 and np.allclose(s[:2], [np.exp(1.0), np.exp(1.8)], rtol=1e-6)

@@ -42,6 +42,21 @@ def test_chain_oracle_matches_reference(name):
     assert np.array_equal(v2, out["sim_weight"]) and np.array_equal(i2, out["sim_indices"])
 
 
+@pytest.mark.parametrize("name", ["knn_rand_tiny", "knn_rand_cifar100", "knn_clustered", "knn_rand_ragged"])
+def test_torch_cpu_port_matches_reference(name):
+    """The timed cpu_baseline port (oracle/knn_torch_cpu.py), un-chunked and chunked."""
+    import torch
+    from oracle import knn_torch_cpu as kt
+    z = P.load_case(name)
+    f = torch.from_numpy(z["feature"])
+    bank = torch.from_numpy(np.ascontiguousarray(z["bank_rows"].T))
+    lab = torch.from_numpy(z["labels"])
+    full = kt.knn_predict_chunked(f, bank, lab, z["classes"], z["knn_k"], z["knn_t"]).numpy()
+    assert np.array_equal(full, z["pred_labels"])
+    part = kt.knn_predict_chunked(f, bank, lab, z["classes"], z["knn_k"], z["knn_t"], chunk=5).numpy()
+    P.check_top1(part, z["pred_labels"], z["pred_scores"], name)
+
+
 def test_exact_cases_are_order_independent():
     for name in P.EXACT_CASES:
         z = P.load_case(name)
