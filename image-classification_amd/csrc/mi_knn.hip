@@ -62,7 +62,7 @@ struct ProfScope {
     ~ProfScope()
     {
         if (!on) return;
-        hipEventRecord(r.e1, s);
+        (void)hipEventRecord(r.e1, s);
         std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(r);
     }
@@ -206,6 +206,7 @@ struct Plan {
 };
 
 constexpr int S0_COLS = 2048;
+constexpr int64_t CAND_BUDGET_BYTES = 4ll << 30;   // soft cap of the candidate buffer
 
 Plan make_plan(int64_t B, int64_t N, int k)
 {
@@ -214,10 +215,16 @@ Plan make_plan(int64_t B, int64_t N, int k)
     pl.qtiles = pl.B_pad / mi::TILE;
     pl.pq = (int)ceil_div(pl.qtiles, mi::PATCH_Q);
     pl.s0_cols = (int)(N < S0_COLS ? N : S0_COLS);
-    // Filter stage: enough patches for >= 3 rounds on every XCD, a multiple of 8 patches so the
-    // 8 XCDs finish together, and never more columns than remain.
+    // Filter stage size.  Larger stages mean fewer launches, a shorter tail per launch and fewer
+    // threshold-refresh (select) passes; the price is the worst-case candidate buffer
+    // (B_pad x stage columns x 8 B), so grow the stage up to a memory budget.  Lower bound: enough
+    // patches for >= 3 rounds on every XCD; always a multiple of 8 patches when possible so the 8 XCDs
+    // finish together; never more columns than remain.
     const int step = 8 / gcd(pl.pq, 8);
     int pn = (int)round_up(ceil_div(24, pl.pq), step);
+    const int64_t budget_cols = CAND_BUDGET_BYTES / ((int64_t)pl.B_pad * 8);
+    const int pn_budget = (int)(budget_cols / (mi::PATCH_N * mi::TILE)) / step * step;
+    if (pn_budget > pn) pn = pn_budget;
     const int64_t remaining = N - pl.s0_cols;
     const int64_t need = ceil_div(remaining > 0 ? remaining : 1, (int64_t)mi::PATCH_N * mi::TILE);
     if (pn > need) pn = (int)need;
@@ -266,7 +273,7 @@ int mi_profile_enable(int on)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
     if (!g_prof_on) {
-        for (auto &r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        for (auto &r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         g_prof.clear();
     }
     return MI_OK;
@@ -286,8 +293,8 @@ int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *to
         ms += t;
         work += r.work;
         ++n;
-        hipEventDestroy(r.e0);
-        hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
     }
     g_prof.swap(keep);
     if (total_ms) *total_ms = ms;
@@ -416,7 +423,14 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
         col += ncols;
         if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
         {
+            // threshold refresh: wave-per-row merge for rows with few candidates, block sort for the rest
             ProfScope ps(MI_PROF_SELECT, (double)B * k * 16.0, s);
+            sel.skip_small = 1;
+            const dim3 mgrid((unsigned)ceil_div(B, 4));
+            if (k <= 256) hipLaunchKernelGGL((mi::merge_kernel<4>), mgrid, dim3(256), 0, s, sel);
+            else if (k <= 512) hipLaunchKernelGGL((mi::merge_kernel<8>), mgrid, dim3(256), 0, s, sel);
+            else hipLaunchKernelGGL((mi::merge_kernel<16>), mgrid, dim3(256), 0, s, sel);
+            HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
             HIP_CHECK(hipGetLastError());
         }

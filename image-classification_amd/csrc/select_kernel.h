@@ -52,6 +52,8 @@ __device__ __forceinline__ void bitonic_sort_desc(unsigned long long *keys, int 
     }
 }
 
+constexpr int MERGE_MAX_NEW = 64;     // rows with <= 64 new candidates take the wave-per-row merge path
+
 struct SelectParams {
     // candidate sources
     const uint2 *cand;          // SRC_LIST : [B_pad, cap] (value bits, row);  SRC_DENSE: float [B_pad][2*cap]
@@ -71,6 +73,7 @@ struct SelectParams {
     float *out_val;             // [B, k]
     long long *out_idx;         // [B, k]
     long long idx_base;
+    int skip_small;             // SRC_LIST: rows with <= MERGE_MAX_NEW candidates were merged by merge_kernel
 };
 
 template <int SRC>
@@ -92,6 +95,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams 
     }
     const bool finalize = p.out_val != nullptr;
     if (n_new == 0 && !finalize) return;
+    if constexpr (SRC == SRC_LIST) {
+        if (p.skip_small && n_new <= MERGE_MAX_NEW) return;
+    }
 
     int n_cur = 0;
     if constexpr (SRC != SRC_GATHER) {
@@ -153,6 +159,98 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams 
             p.out_val[(long long)row * p.k + i] = ok ? key_value(keys[i]) : -INFINITY;
             p.out_idx[(long long)row * p.k + i] =
                 ok ? (SRC == SRC_GATHER ? (long long)key_row(keys[i]) : p.idx_base + (long long)key_row(keys[i])) : -1ll;
+        }
+    }
+}
+
+// Wave-per-row merge: the common case after the first few stages is a handful of new candidates
+// per row.  One wave holds the row's sorted top-k in registers (KPL keys per lane, key i on lane
+// i % 64) and its <= 64 new candidates one per lane, and computes every key's position in the
+// merged order by counting -- no LDS, no barrier, no sort:
+//   new key c   -> position = #prev > c + #new > c
+//   prev key i  -> position = i + #new > prev_i
+// Keys whose position is unchanged are not rewritten.  Rows with more than MERGE_MAX_NEW candidates
+// are left to select_kernel<SRC_LIST> (skip_small = 1), which is launched right after.
+template <int KPL>
+__global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B) return;
+    const unsigned c = p.cnt[row];
+    const bool finalize = p.out_val != nullptr;
+    if (c > (unsigned)MERGE_MAX_NEW || (c == 0 && !finalize)) return;
+    const int n_new = (int)c;
+    const int k = p.k;
+    const int n_cur = p.topk_n[row];
+    unsigned long long *topk = p.topk + row * k;
+
+    unsigned long long pk[KPL];
+    int shift[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int i = j * 64 + lane;
+        pk[j] = i < n_cur ? topk[i] : 0ull;
+        shift[j] = 0;
+    }
+    unsigned long long ck = 0ull;
+    if (lane < n_new) {
+        const uint2 cd = p.cand[row * p.cap + lane];
+        ck = make_key(__uint_as_float(cd.x), cd.y);
+    }
+    const int n_valid_new = __popcll(__ballot(ck != 0ull));
+    int my_pos = 0;
+    for (int l = 0; l < n_new; ++l) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)ck, l);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(ck >> 32), l);
+        const unsigned long long cl = ((unsigned long long)hi << 32) | lo;     // wave-uniform
+        if (cl == 0ull) continue;
+        int above = __popcll(__ballot(ck > cl));                                 // #new > c_l
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const bool gt = pk[j] > cl;                                          // empty slots (0) never are
+            above += __popcll(__ballot(gt));                                     // #prev > c_l
+            shift[j] += (pk[j] != 0ull && !gt) ? 1 : 0;                          // c_l outranks prev_i
+        }
+        if (lane == l) my_pos = above;
+    }
+    const int n_out = (n_cur + n_valid_new) < k ? (n_cur + n_valid_new) : k;
+    // scatter to the merged positions (all reads above are complete: the stores depend on them)
+    if (ck != 0ull && my_pos < k) {
+        topk[my_pos] = ck;
+        if (my_pos == k - 1) p.tau[row] = key_value(ck);
+    }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int i = j * 64 + lane;
+        const int np = i + shift[j];
+        if (pk[j] != 0ull && shift[j] > 0 && np < k) {
+            topk[np] = pk[j];
+            if (np == k - 1) p.tau[row] = key_value(pk[j]);
+        }
+    }
+    if (lane == 0) {
+        p.topk_n[row] = n_out;
+        p.cnt[row] = 0u;
+    }
+    if (finalize) {
+        // positions are final; emit (value, index) for every slot of this row from the merged keys
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int i = j * 64 + lane;
+            const int np = i + shift[j];
+            if (pk[j] != 0ull && np < k) {
+                p.out_val[row * k + np] = key_value(pk[j]);
+                p.out_idx[row * k + np] = p.idx_base + (long long)key_row(pk[j]);
+            }
+        }
+        if (ck != 0ull && my_pos < k) {
+            p.out_val[row * k + my_pos] = key_value(ck);
+            p.out_idx[row * k + my_pos] = p.idx_base + (long long)key_row(ck);
+        }
+        for (int i = n_out + lane; i < k; i += 64) {
+            p.out_val[row * k + i] = -INFINITY;
+            p.out_idx[row * k + i] = -1ll;
         }
     }
 }

@@ -33,10 +33,15 @@ def gather(value: torch.Tensor) -> torch.Tensor:
     value = value.contiguous()
     if value.dim() == 0:
         value = value[None]
-    out = torch.empty((dist.get_world_size() * value.shape[0],) + tuple(value.shape[1:]),
-                      dtype=value.dtype, device=value.device)
-    dist.all_gather_into_tensor(out, value)
-    return out
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl":            # RCCL on ROCm
+        out = torch.empty((world * value.shape[0],) + tuple(value.shape[1:]), dtype=value.dtype, device=value.device)
+        dist.all_gather_into_tensor(out, value)
+        return out
+    host = value.cpu()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host)
+    return torch.cat(parts, dim=0).to(value.device)
 
 
 def _need_gpu(t: torch.Tensor, what: str) -> None:

@@ -98,10 +98,16 @@ class ShardedKnn:
         if dist.get_backend(self.group) == "nccl":
             w1 = dist.all_gather_into_tensor(gv, val.contiguous(), group=self.group, async_op=True)
             w2 = dist.all_gather_into_tensor(gi, idx.contiguous(), group=self.group, async_op=True)
-        else:
-            w1 = dist.all_gather(list(gv.unbind(0)), val.contiguous(), group=self.group, async_op=True)
-            w2 = dist.all_gather(list(gi.unbind(0)), idx.contiguous(), group=self.group, async_op=True)
-        return gv, gi, (w1, w2)
+            return gv, gi, (w1, w2)
+        # any other backend (gloo in the tests): synchronous, staged through host memory
+        hv, hi = val.cpu().contiguous(), idx.cpu().contiguous()
+        lv = [torch.empty_like(hv) for _ in range(G)]
+        li = [torch.empty_like(hi) for _ in range(G)]
+        dist.all_gather(lv, hv, group=self.group)
+        dist.all_gather(li, hi, group=self.group)
+        gv.copy_(torch.stack(lv))
+        gi.copy_(torch.stack(li))
+        return gv, gi, ()
 
     def _local_candidates(self, f: torch.Tensor, k: int):
         """Local top-k padded to k columns with (-inf, -1) when this shard holds fewer than k rows."""

@@ -47,6 +47,8 @@ def make_case(seed=0, B=50, N=1203, D=32, C=7):
 
 
 def main(rank, world, port, use_gpu, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)      # a hang names its line instead of timing out silently
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
