@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi_knn.so")
+LIB_PATH = os.environ.get("MI_KNN_LIB") or os.path.join(HERE, "libmi_knn.so")   # override: experiments only
 
 MI_F32, MI_BF16 = 0, 1
 MI_MAX_K, MI_MAX_CLASSES = 1024, 65536

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mi {
 
 constexpr int DT_F32 = 0, DT_BF16 = 1;
@@ -35,6 +37,8 @@ constexpr int KSTEP_BYTES = 128;          // bytes of one row per K-step
 constexpr int OPERAND_TILE_BYTES = TILE * KSTEP_BYTES;       // 32 KiB
 constexpr int STAGE_BYTES = 2 * OPERAND_TILE_BYTES;          // A + B
 constexpr int SIM_LDS_BYTES = 2 * STAGE_BYTES;               // double buffered: 128 KiB
+constexpr int SIM_EXTRA_LDS = 1024;                         // thresholds of the tile's 256 rows
+constexpr int LCAND = 32;                                  // LDS candidate slots per row and tile
 constexpr int SIM_THREADS = 512;
 constexpr int PATCH_Q = 8, PATCH_N = 4;   // tiles of one XCD patch (8 query tiles x 4 bank tiles)
 
@@ -67,7 +71,7 @@ struct SimParams {
 template <int DT, int MODE>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[SIM_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[SIM_LDS_BYTES + SIM_EXTRA_LDS];
 
     // ---- block -> tile.  Blocks b and b+8 share an XCD (round-robin dispatch), an XCD holds 32
     // resident blocks (one per CU: 128 KiB LDS), so 32 consecutive same-XCD blocks form one patch
@@ -98,19 +102,34 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         int qa = q0 + r; qa = qa < p.B ? qa : p.B - 1;             // clamp: padding rows re-read a valid row
         int xb = n0 + r; xb = xb < p.N ? xb : p.N - 1;
+#if defined(MI_ABLATE) && (MI_ABLATE & 1)
+        xb = r;                                                      // timing-only: bank tile 0 for everyone
+#endif
+#if defined(MI_ABLATE) && (MI_ABLATE & 4)
+        qa = r;                                                      // timing-only: query tile 0 for everyone
+#endif
         a_src[i] = p.q + (long long)qa * p.ldq_bytes + chunk * 16;
         b_src[i] = p.x + (long long)xb * p.ldx_bytes + chunk * 16;
     }
-    auto stage = [&](int t, int buf) {
-        char *base = smem + buf * STAGE_BYTES + w * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(a_src[i] + (long long)t * KSTEP_BYTES),
-                                             (AS3 void *)(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(b_src[i] + (long long)t * KSTEP_BYTES),
-                                             (AS3 void *)(base + OPERAND_TILE_BYTES + i * 1024), 16, 0, 0);
-        }
+    // The DMA is issued from inline asm on purpose: with the global_load_lds BUILTIN in the loop,
+    // hipcc (ROCm 7.2) turns every counted LDS wait of the loop into lgkmcnt(0) and the operand-read
+    // pipelining below is lost.  Hidden from the compiler, the loads are counted by hand: one
+    // `s_waitcnt vmcnt(0)` in front of the K-step's barrier.  M0 (LDS destination base) is saved
+    // and restored inside the statement.  One call stages row group 4w+i of A and of B (2 KiB).
+    auto stage_pair = [&](int i, int t, int buf) {
+        const unsigned base = (unsigned)(size_t)(AS3 char *)(smem + buf * STAGE_BYTES + w * 4096 + i * 1024);
+        const long long koff = (long long)t * KSTEP_BYTES;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a], off\n\t"
+            "s_mov_b32 m0, %[lb]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b], off\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [la] "s"(base), [lb] "s"(base + OPERAND_TILE_BYTES), [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
+            : "memory");
     };
+    auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     // ---- MFMA operand read offsets.  Lane reads row (lane & 15) of a 16-row block; K chunk
     // (lane >> 4) [+4 for the second half of the K-step]; swizzle term depends on the lane only.
@@ -119,54 +138,126 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     const int a_row_off = (wm * 128 + lr) * KSTEP_BYTES;
     const int b_row_off = OPERAND_TILE_BYTES + (wn * 64 + lr) * KSTEP_BYTES;
 
+    if constexpr (MODE == MODE_FILTER) {
+        // thresholds of this tile's 256 query rows -> spare LDS (read back in the epilogue)
+        if (tid < TILE) ((float *)(smem + SIM_LDS_BYTES))[tid] = p.tau[q0 + tid];
+    }
+
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    __syncthreads();
-    for (int t = 0; t < p.ksteps; ++t) {
-        if (t + 1 < p.ksteps) stage(t + 1, (t + 1) & 1);
+#define MI_RD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define MI_MM(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    // One K-step: 64 MFMAs per wave in 8 groups of 8.  The operand reads are software pipelined
+    // (the reads of group g+1 are issued before the MFMAs of group g, two register sets) and the
+    // next K-step's DMA is spread over the first four groups (one A + one B piece each) instead of
+    // being issued as a burst: a burst keeps BOTH waves of a SIMD out of the matrix pipe at once.
+    auto kstep = [&](int t, auto dma_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value;
         const char *lds = smem + (t & 1) * STAGE_BYTES;
+        const int nbuf = (t + 1) & 1;
         if constexpr (DT == DT_BF16) {
+            const int coff0 = (lq ^ sw) * 16, coff1 = coff0 ^ 64;
+            const char *la = lds + a_row_off, *lb = lds + b_row_off;
+            bf16x8 b0[4], b1[4], a0[2], a1[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int coff = ((lq ^ sw) ^ (s << 2)) * 16;
-                bf16x8 af[8], bf[4];
+            for (int j = 0; j < 4; ++j) b0[j] = *(const bf16x8 *)(lb + j * 2048 + coff0);
+            a0[0] = *(const bf16x8 *)(la + coff0);
+            a0[1] = *(const bf16x8 *)(la + 2048 + coff0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    af[i] = *(const bf16x8 *)(lds + a_row_off + i * 16 * KSTEP_BYTES + coff);
+            for (int pr = 0; pr < 8; ++pr) {          // pr = s * 4 + pair
+                const int s = pr >> 2, pp = pr & 3;
+                bf16x8 *ac = (pr & 1) ? a1 : a0, *an = (pr & 1) ? a0 : a1;
+                bf16x8 *bc = s ? b1 : b0;
+                if constexpr (DMA) {
+                    if (pr < 4) stage_pair(pr, t + 1, nbuf);
+                }
+                if (pr < 7) {
+                    const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;
+                    const int co = ns ? coff1 : coff0;
+                    an[0] = *(const bf16x8 *)(la + (2 * np) * 2048 + co);
+                    an[1] = *(const bf16x8 *)(la + (2 * np + 1) * 2048 + co);
+                    if (pr == 3) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bf[j] = *(const bf16x8 *)(lds + b_row_off + j * 16 * KSTEP_BYTES + coff);
+                        for (int j = 0; j < 4; ++j) b1[j] = *(const bf16x8 *)(lb + j * 2048 + coff1);
+                    }
+                }
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[2 * pp + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[u], bc[j], acc[2 * pp + u][j], 0, 0, 0);
             }
+            // pin that interleave (hipcc otherwise sinks every read to just before its first use)
+            MI_RD(6);
+            MI_RD(2); MI_MM(8);
+            MI_RD(2); MI_MM(8);
+            MI_RD(2); MI_MM(8);
+            MI_RD(6); MI_MM(8);
+            MI_RD(2); MI_MM(8);
+            MI_RD(2); MI_MM(8);
+            MI_RD(2); MI_MM(8);
+            MI_MM(8);
         } else {
+            // f32: 8 sub-steps of 4 k each; v_mfma_f32_16x16x4_f32 chains k ascending (bit-exact order)
+            const char *la = lds + a_row_off, *lb = lds + b_row_off;
+            float a0[8], a1[8], b0[4], b1[4];
+            {
+                const int co = (sw * 16) + lq * 4;          // kk = 0
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a0[i] = *(const float *)(la + i * 2048 + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b0[j] = *(const float *)(lb + j * 2048 + co);
+            }
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                const int coff = ((kk ^ sw) * 16) + lq * 4;
-                float af[8], bf[4];
+                float *ac = (kk & 1) ? a1 : a0, *an = (kk & 1) ? a0 : a1;
+                float *bc = (kk & 1) ? b1 : b0, *bn = (kk & 1) ? b0 : b1;
+                if constexpr (DMA) {
+                    if (kk < 4) stage_pair(kk, t + 1, nbuf);
+                }
+                if (kk < 7) {
+                    const int co = (((kk + 1) ^ sw) * 16) + lq * 4;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    af[i] = *(const float *)(lds + a_row_off + i * 16 * KSTEP_BYTES + coff);
+                    for (int i = 0; i < 8; ++i) an[i] = *(const float *)(la + i * 2048 + co);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bf[j] = *(const float *)(lds + b_row_off + j * 16 * KSTEP_BYTES + coff);
+                    for (int j = 0; j < 4; ++j) bn[j] = *(const float *)(lb + j * 2048 + co);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i], bc[j], acc[i][j], 0, 0, 0);
             }
+            MI_RD(12);
+            MI_RD(12); MI_MM(32);
+            MI_RD(12); MI_MM(32);
+            MI_RD(12); MI_MM(32);
+            MI_RD(12); MI_MM(32);
+            MI_RD(12); MI_MM(32);
+            MI_RD(12); MI_MM(32);
+            MI_RD(12); MI_MM(32);
+            MI_MM(32);
         }
+        stage_wait();
         __syncthreads();
-    }
+    };
+#undef MI_RD
+#undef MI_MM
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_pair(i, 0, 0);
+    stage_wait();
+    __syncthreads();
+#if defined(MI_ABLATE) && (MI_ABLATE & 2)
+    for (int t = 0; t < p.ksteps; ++t) kstep(t, std::false_type{});          // timing-only: no DMA in the loop
+#else
+    for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{});
+    kstep(p.ksteps - 1, std::false_type{});
+#endif
 
     // ---- epilogue.  C/D map of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int row_base = q0 + wm * 128 + lq * 4;          // + i*16 + reg
@@ -188,36 +279,72 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 }
             }
     } else if constexpr (MODE == MODE_FILTER) {
-        // tau is padded to a multiple of 256 rows (+inf on padding): no row bound needed here.
-        f32x4 tau[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tau[i] = *(const f32x4 *)(p.tau + row_base + i * 16);
-        bool colok[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) colok[j] = (col_base + j * 16) < col_end;
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) any |= (colok[j] && acc[i][j][r] >= tau[i][r]);
-        if (__any(any)) {
+#if defined(MI_ABLATE) && (MI_ABLATE & 8)
+        {   // timing-only: keep the accumulators live, emit (almost) nothing
+            float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[i][j][r];
-                        const int row = row_base + i * 16 + r;
-                        if (colok[j] && v >= tau[i][r] && row < p.B) {
-                            const unsigned slot = atomicAdd(p.cnt + row, 1u);
-                            if (slot < (unsigned)p.cap)
-                                p.cand[(long long)row * p.cap + slot] =
-                                    make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));
+                    for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
+            if (sum == 12345.678f) p.cnt[row_base] = 1u;
+            return;
+        }
+#endif
+        // Candidates are staged in LDS (free after the K loop): an LDS atomic hands out the slot,
+        // then ONE global atomic per row reserves the row's list space and the row's entries are
+        // copied out.  (Returning GLOBAL atomics per candidate serialise a wave: ~25/stage-index
+        // candidates per wave and tile at ~1.5 us each cost 19 % of the kernel.)
+        unsigned *lcnt = (unsigned *)smem;                         // [256]
+        uint2 *llist = (uint2 *)(smem + 1024);                     // [256][LCAND]
+        const float *ltau = (const float *)(smem + SIM_LDS_BYTES); // [256] staged at kernel start
+        if (tid < TILE) lcnt[tid] = 0u;
+        __syncthreads();
+        f32x4 tau[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tau[i] = *(const f32x4 *)(ltau + wm * 128 + lq * 4 + i * 16);
+        bool colok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) colok[j] = (col_base + j * 16) < col_end;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = tau[i][r];
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) any |= (colok[j] && acc[i][j][r] >= t);
+                if (__any(any)) {
+                    const int rl = wm * 128 + lq * 4 + i * 16 + r;        // row within the tile
+                    if (q0 + rl < p.B) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[i][j][r];
+                            if (colok[j] && v >= t) {
+                                const uint2 e = make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));
+                                const unsigned sl = atomicAdd(lcnt + rl, 1u);
+                                if (sl < (unsigned)LCAND) {
+                                    llist[rl * LCAND + sl] = e;
+                                } else {                                    // LDS list full: straight to HBM
+                                    const unsigned slot = atomicAdd(p.cnt + q0 + rl, 1u);
+                                    if (slot < (unsigned)p.cap) p.cand[(long long)(q0 + rl) * p.cap + slot] = e;
+                                }
+                            }
                         }
                     }
+                }
+            }
+        __syncthreads();
+        if (tid < TILE) {
+            unsigned n = lcnt[tid];
+            n = n < (unsigned)LCAND ? n : (unsigned)LCAND;
+            if (n) {
+                const long long row = q0 + tid;
+                const unsigned base = atomicAdd(p.cnt + row, n);
+                for (unsigned e = 0; e < n; ++e)
+                    if (base + e < (unsigned)p.cap) p.cand[row * p.cap + base + e] = llist[tid * LCAND + e];
+            }
         }
     } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over this wave's 64 columns
 #pragma unroll
