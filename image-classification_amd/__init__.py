@@ -6,6 +6,7 @@ Import as ``image_classification_amd`` (alias module at the repository root)."""
 from . import _lib
 from .knn import BankIndex, knn_merge, knn_predict, knn_predict_full, knn_topk, knn_vote, pack_rows
 from .memory_bank import MemoryBank, StorageBank
+from .moco import contrastive_loss2, moco_queue_loss
 
 __all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex",
-           "pack_rows", "MemoryBank", "StorageBank", "_lib"]
+           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "_lib"]

@@ -12,12 +12,12 @@ LIB_PATH = os.environ.get("MI_KNN_LIB") or os.path.join(HERE, "libmi_knn.so")   
 
 MI_F32, MI_BF16 = 0, 1
 MI_MAX_K, MI_MAX_CLASSES = 1024, 65536
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes",
     "mi_knn_topk", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
-    "mi_moco_fwd", "mi_moco_bwd",
+    "mi_moco_fwd", "mi_moco_bwd", "mi_queue_push_stash",
 ]
 
 
@@ -63,7 +63,9 @@ def lib() -> ctypes.CDLL:
     L.mi_moco_fwd.restype = i32
     L.mi_moco_fwd.argtypes = [p, p, p, i64, i64, i64, f32, p, p, p, p, sz, p]
     L.mi_moco_bwd.restype = i32
-    L.mi_moco_bwd.argtypes = [p, p, p, i64, i64, i64, f32, p, p, p, p, p, sz, p]
+    L.mi_moco_bwd.argtypes = [p, p, p, i64, i64, i64, f32, p, p, p, p, p, i64, i64, p, sz, p]
+    L.mi_queue_push_stash.restype = i32
+    L.mi_queue_push_stash.argtypes = [p, i64, i64, i64, p, i64, p, ctypes.POINTER(i64), p]
     if L.mi_abi_version() != ABI_VERSION:
         raise MiKnnError(f"libmi_knn.so ABI {L.mi_abi_version()} != expected {ABI_VERSION}: rebuild")
     _lib = L

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/mi_knn.h"
+#include "moco_kernel.h"
 #include "select_kernel.h"
 #include "sim_kernel.h"
 #include "vote_kernel.h"
@@ -516,8 +517,8 @@ int mi_bank_scatter(void *bank, int64_t K, int64_t row_bytes, const int64_t *ind
 
 // ------------------------------------------------------------------ MoCo queue logits
 namespace {
-struct MocoPlan { int b_pad, ntiles, lse_ld; size_t off_part, off_rowloss, total; };
-MocoPlan moco_plan(int64_t b, int64_t K)
+struct MocoPlan { int b_pad, ntiles, lse_ld; size_t off_part, off_rowloss, fwd_total; int nslices, rows_per_slice; size_t bwd_total, total; };
+MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
 {
     MocoPlan m{};
     m.b_pad = (int)round_up(b, mi::TILE);
@@ -525,7 +526,17 @@ MocoPlan moco_plan(int64_t b, int64_t K)
     m.lse_ld = m.ntiles * 4;
     m.off_part = 0;
     m.off_rowloss = (size_t)round_up((int64_t)m.b_pad * m.lse_ld * 8, 256);
-    m.total = m.off_rowloss + (size_t)round_up((int64_t)m.b_pad * 4, 256);
+    m.fwd_total = m.off_rowloss + (size_t)round_up((int64_t)m.b_pad * 4, 256);
+    // backward: ~256 workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
+    const int64_t qtiles = ceil_div(b, mi::MB_ROWS);
+    const int64_t ktiles = ceil_div(K, mi::MB_ROWS);
+    int64_t ns = ceil_div(256, qtiles);
+    if (ns > ktiles) ns = ktiles;
+    if (ns < 1) ns = 1;
+    m.rows_per_slice = (int)(ceil_div(ktiles, ns) * mi::MB_ROWS);
+    m.nslices = (int)ceil_div(K, m.rows_per_slice);
+    m.bwd_total = (size_t)round_up((int64_t)m.nslices * b * D * 4, 256);
+    m.total = m.fwd_total > m.bwd_total ? m.fwd_total : m.bwd_total;
     return m;
 }
 }  // namespace
@@ -533,7 +544,7 @@ MocoPlan moco_plan(int64_t b, int64_t K)
 size_t mi_moco_workspace_bytes(int64_t b, int64_t K, int64_t D)
 {
     if (b <= 0 || K <= 0 || D <= 0) return 0;
-    return moco_plan(b, K).total;
+    return moco_plan(b, K, D).total;
 }
 
 int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
@@ -545,8 +556,8 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
     if (D % 32) return fail(MI_ERR_UNSUPPORTED, "mi_moco_fwd: D=%lld must be a multiple of 32", (long long)D);
     if (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_moco_fwd: q, queue, workspace must be 16-byte aligned");
     if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_moco_fwd: temperature must be positive");
-    const MocoPlan mp = moco_plan(b, K);
-    if (workspace_bytes < mp.total) return fail(MI_ERR_WORKSPACE, "mi_moco_fwd: workspace %zu < required %zu", workspace_bytes, mp.total);
+    const MocoPlan mp = moco_plan(b, K, D);
+    if (workspace_bytes < mp.fwd_total) return fail(MI_ERR_WORKSPACE, "mi_moco_fwd: workspace %zu < required %zu", workspace_bytes, mp.fwd_total);
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     mi::SimParams sp{};
@@ -565,8 +576,9 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
     sp.inv_t = 1.0f / temperature;
     sp.lse_part = (float2 *)(ws + mp.off_part);
     sp.lse_ld = mp.lse_ld;
-    HIP_CHECK((launch_sim<mi::DT_F32, mi::MODE_LSE>(sp, s)));
     float *row_loss = (float *)(ws + mp.off_rowloss);
+    ProfScope ps(MI_PROF_MOCO_FWD, 2.0 * (double)b * (double)(K + 1) * (double)D, s);
+    HIP_CHECK((launch_sim<mi::DT_F32, mi::MODE_LSE>(sp, s)));
     hipLaunchKernelGGL(moco_combine_kernel, dim3((unsigned)b), dim3(64), 0, s, q, key, (int)D, sp.lse_part, mp.lse_ld, mp.lse_ld, sp.inv_t, lse, lpos, row_loss);
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)b, loss);
@@ -577,11 +589,73 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
 int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
                 int64_t D, float temperature, const float *lse, const float *lpos,
                 const float *grad_loss, float *dq,
+                const float *patch_rows, int64_t patch_lo, int64_t patch_n,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream)
 {
-    (void)q; (void)key; (void)queue; (void)b; (void)K; (void)D; (void)temperature; (void)lse; (void)lpos;
-    (void)grad_loss; (void)dq; (void)workspace; (void)workspace_bytes; (void)stream;
-    return fail(MI_ERR_UNSUPPORTED, "mi_moco_bwd: not built yet");
+    if (!q || !key || !queue || !lse || !lpos || !grad_loss || !dq || !workspace) return fail(MI_ERR_ARG, "mi_moco_bwd: null pointer");
+    if (b < 1 || K < 1 || D < 1 || b > (1 << 24) || K > INT32_MAX - 2 * mi::TILE) return fail(MI_ERR_ARG, "mi_moco_bwd: bad shape");
+    if (D % 64 || D > 256) return fail(MI_ERR_UNSUPPORTED, "mi_moco_bwd: D=%lld must be a multiple of 64 and at most 256", (long long)D);
+    if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_moco_bwd: temperature must be positive");
+    if (patch_n < 0 || patch_lo < 0 || patch_lo + patch_n > K || (patch_n > 0 && !patch_rows)) return fail(MI_ERR_ARG, "mi_moco_bwd: bad patch range [%lld, +%lld) for K=%lld", (long long)patch_lo, (long long)patch_n, (long long)K);
+    if (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)workspace | (uintptr_t)patch_rows | (uintptr_t)dq) & 15) return fail(MI_ERR_ARG, "mi_moco_bwd: q, queue, patch_rows, dq, workspace must be 16-byte aligned");
+    const MocoPlan mp = moco_plan(b, K, D);
+    if (workspace_bytes < mp.bwd_total) return fail(MI_ERR_WORKSPACE, "mi_moco_bwd: workspace %zu < required %zu", workspace_bytes, mp.bwd_total);
+    hipStream_t s = (hipStream_t)stream;
+    mi::MocoBwdParams bp{};
+    bp.q = q;
+    bp.queue = queue;
+    bp.lse = lse;
+    bp.patch = patch_n > 0 ? patch_rows : nullptr;
+    bp.patch_lo = (int)patch_lo;
+    bp.patch_n = (int)patch_n;
+    bp.b = (int)b;
+    bp.K = (int)K;
+    bp.inv_t = 1.0f / temperature;
+    bp.part = (float *)workspace;
+    bp.rows_per_slice = mp.rows_per_slice;
+    const dim3 grid((unsigned)ceil_div(b, mi::MB_ROWS), (unsigned)mp.nslices);
+    const size_t lds = mi::moco_bwd_lds_bytes((int)D);
+    {
+        ProfScope ps(MI_PROF_MOCO_BWD, 4.0 * (double)b * (double)K * (double)D, s);
+#define MI_LAUNCH_BWD(D64)                                                                                       \
+        do {                                                                                                    \
+            HIP_CHECK(hipFuncSetAttribute((const void *)mi::moco_bwd_kernel<D64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((mi::moco_bwd_kernel<D64>), grid, dim3(mi::MB_THREADS), lds, s, bp);             \
+        } while (0)
+        switch ((int)(D / 64)) {
+        case 1: MI_LAUNCH_BWD(1); break;
+        case 2: MI_LAUNCH_BWD(2); break;
+        case 3: MI_LAUNCH_BWD(3); break;
+        default: MI_LAUNCH_BWD(4); break;
+        }
+#undef MI_LAUNCH_BWD
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(mi::moco_bwd_reduce_kernel, dim3((unsigned)ceil_div(b * D, 256)), dim3(256), 0, s,
+                           (const float *)workspace, mp.nslices, (int)b, (int)D, key, lse, lpos, grad_loss, bp.inv_t, dq);
+        HIP_CHECK(hipGetLastError());
+    }
+    return MI_OK;
+}
+
+int mi_queue_push_stash(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
+                        const void *value, int64_t b, void *stash, int64_t *new_ptr, mi_stream_t stream)
+{
+    if (!queue || !value || !stash) return fail(MI_ERR_ARG, "mi_queue_push_stash: null pointer");
+    if (K < 1 || row_bytes < 1 || b < 0 || ptr < 0 || ptr >= K) return fail(MI_ERR_ARG, "mi_queue_push_stash: bad shape K=%lld row_bytes=%lld b=%lld ptr=%lld", (long long)K, (long long)row_bytes, (long long)b, (long long)ptr);
+    const int64_t w = b < K - ptr ? b : K - ptr;       // truncating, as mi_queue_push
+    if (w > 0) {
+        char *dst = (char *)queue + ptr * row_bytes;
+        const long long bytes = w * row_bytes;
+        const bool vec = ((((uintptr_t)dst | (uintptr_t)value | (uintptr_t)stash) & 15) == 0 && (bytes & 15) == 0);
+        const long long items = vec ? bytes >> 4 : bytes;
+        int grid = (int)ceil_div(items, 256);
+        if (grid > 2048) grid = 2048;
+        if (vec) hipLaunchKernelGGL(mi::push_stash_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)value, (uint4 *)stash, items);
+        else hipLaunchKernelGGL(mi::push_stash_bytes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, (const char *)value, (char *)stash, items);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (new_ptr) *new_ptr = (ptr + w) % K;
+    return MI_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,193 @@
+// moco_kernel.h -- backward of the MoCo queue InfoNCE w.r.t. the query (track_ssl/moco.py:152-156,172).
+//
+//   p[i][n] = exp(q_i . queue_n / T - lse_i)                       (softmax over [pos, queue])
+//   dq_i    = g / (b T) * ( sum_n p[i][n] queue_n + (p_pos[i] - 1) key_i )
+//
+// The [b, K] logits / probabilities are never written: a workgroup owns 64 query rows and one
+// slice of the queue, recomputes S = q . queue_tile^T for 64 queue rows at a time with fp32 MFMA,
+// turns it into P in registers, transposes P through a wave-private LDS patch and accumulates
+// P . queue_tile into its [64, D] partial of dq (fp32 MFMA again).  Slices are summed by a second
+// kernel in slice order, so the result does not depend on scheduling.
+//
+// The queue may have been overwritten between forward and backward (MemoryBank.push precedes
+// backward at moco.py:159-172).  Instead of the reference's full clone() per step the caller
+// stashes only the overwritten rows: rows [patch_lo, patch_lo + patch_n) are read from `patch`.
+//
+// MFMA operand maps (v_mfma_f32_16x16x4_f32): A lane -> (row = lane & 15, k = lane >> 4),
+// B lane -> (col = lane & 15, k = lane >> 4), C/D lane -> (col = lane & 15, row = 4 * (lane >> 4) + reg).
+// Both GEMMs feed A and B with the SAME permutation of k (a lane's float4 holds 4 k values used
+// by 4 consecutive MFMAs), which keeps every LDS read a conflict-free 128-bit access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+constexpr int MB_ROWS = 64;        // query rows and queue rows per tile
+constexpr int MB_THREADS = 256;    // 4 waves, wave w owns query rows 16w .. 16w+15
+constexpr int MB_PLD = 68;         // leading dimension of the wave-private P patch
+
+struct MocoBwdParams {
+    const float *q;            // [b, D]
+    const float *queue;        // [K, D]
+    const float *lse;          // [b]
+    const float *patch;        // [patch_n, D] pre-push contents of queue rows [patch_lo, patch_lo + patch_n), or nullptr
+    int patch_lo, patch_n;
+    int b, K;
+    float inv_t;
+    float *part;               // [nslices, b, D]
+    int rows_per_slice;        // multiple of MB_ROWS
+};
+
+inline size_t moco_bwd_lds_bytes(int D) { return (size_t)(2 * MB_ROWS * (D + 4) + 4 * 16 * MB_PLD) * 4; }
+
+template <int D64>             // D / 64
+__global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParams p)
+{
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int D = D64 * 64, LD = D + 4;
+    constexpr int LOADS = MB_ROWS * D / 4 / MB_THREADS;      // float4 per thread and tile = D / 16
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sq = lds;                       // [64][LD] query tile
+    float *sx = sq + MB_ROWS * LD;         // [64][LD] queue tile
+    float *sp = sx + MB_ROWS * LD;         // [4][16][MB_PLD] P, one patch per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int q0 = blockIdx.x * MB_ROWS;
+    const int n_begin = blockIdx.y * p.rows_per_slice;
+    const int n_end = (n_begin + p.rows_per_slice) < p.K ? (n_begin + p.rows_per_slice) : p.K;
+
+    auto tile_row_ptr = [&](int n) -> const float * {
+        if (n >= p.patch_lo && n < p.patch_lo + p.patch_n) return p.patch + (long long)(n - p.patch_lo) * D;
+        return p.queue + (long long)n * D;
+    };
+    float4 pre[LOADS];
+    auto prefetch = [&](int n0) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
+            const int n = n0 + r;
+            pre[i] = n < n_end ? *(const float4 *)(tile_row_ptr(n) + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
+            *(float4 *)(sx + r * LD + c * 4) = pre[i];
+        }
+    };
+
+    // query tile -> LDS (rows past b are zero and get lse = +inf below: their P is exactly 0)
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
+        const int row = q0 + r;
+        *(float4 *)(sq + r * LD + c * 4) =
+            row < p.b ? *(const float4 *)(p.q + (long long)row * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float lse_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q0 + 16 * w + 4 * lq + r;
+        lse_r[r] = row < p.b ? p.lse[row] : INFINITY;
+    }
+    f32x4 acc[D64 * 4];
+#pragma unroll
+    for (int i = 0; i < D64 * 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float *spw = sp + w * 16 * MB_PLD;
+    if (n_begin < n_end) prefetch(n_begin);
+    for (int n0 = n_begin; n0 < n_end; n0 += MB_ROWS) {
+        __syncthreads();                       // everyone is done reading the previous tile
+        commit();
+        __syncthreads();
+        if (n0 + MB_ROWS < n_end) prefetch(n0 + MB_ROWS);     // in flight during both GEMMs
+
+        // S[16 x 64] = q rows (16w ..) . tile rows^T
+        f32x4 s[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < D / 16; ++g) {
+            const float4 a = *(const float4 *)(sq + (16 * w + lr) * LD + 16 * g + 4 * lq);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float4 x = *(const float4 *)(sx + (16 * nb + lr) * LD + 16 * g + 4 * lq);
+                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, s[nb], 0, 0, 0);
+                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, s[nb], 0, 0, 0);
+                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, s[nb], 0, 0, 0);
+                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, s[nb], 0, 0, 0);
+            }
+        }
+        // P = exp(S / T - lse), columns past the slice end are 0; C layout -> LDS patch [row][n]
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const bool ok = (n0 + 16 * nb + lr) < n_end;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                spw[(4 * lq + r) * MB_PLD + 16 * nb + lr] = ok ? __expf(s[nb][r] * p.inv_t - lse_r[r]) : 0.f;
+        }
+        __syncthreads();
+        // dq[16 x D] += P[16 x 64] . tile[64 x D]; block c*4+j holds columns 64c + 4*(lane&15) + j
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a = spw[lr * MB_PLD + 4 * kk + lq];
+#pragma unroll
+            for (int c = 0; c < D64; ++c) {
+                const float4 x = *(const float4 *)(sx + (4 * kk + lq) * LD + 64 * c + 4 * lr);
+                acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.x, acc[c * 4 + 0], 0, 0, 0);
+                acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.y, acc[c * 4 + 1], 0, 0, 0);
+                acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.z, acc[c * 4 + 2], 0, 0, 0);
+                acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.w, acc[c * 4 + 3], 0, 0, 0);
+            }
+        }
+    }
+    // partial of this slice
+    float *part = p.part + (long long)blockIdx.y * p.b * D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q0 + 16 * w + 4 * lq + r;
+        if (row < p.b) {
+#pragma unroll
+            for (int c = 0; c < D64; ++c)
+                *(float4 *)(part + (long long)row * D + 64 * c + 4 * lr) =
+                    make_float4(acc[c * 4 + 0][r], acc[c * 4 + 1][r], acc[c * 4 + 2][r], acc[c * 4 + 3][r]);
+        }
+    }
+}
+
+// dq[i][d] = g * inv_t / b * ( sum_s part[s][i][d] + (exp(lpos_i * inv_t - lse_i) - 1) * key[i][d] )
+__global__ __launch_bounds__(256) void moco_bwd_reduce_kernel(const float *part, int nslices, int b, int D,
+                                                              const float *key, const float *lse, const float *lpos,
+                                                              const float *grad_loss, float inv_t, float *dq)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)b * D) return;
+    const int row = (int)(e / D);
+    float s = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) s += part[(long long)sl * b * D + e];
+    const float ppos = __expf(lpos[row] * inv_t - lse[row]);
+    dq[e] = grad_loss[0] * inv_t / (float)b * (s + (ppos - 1.f) * key[e]);
+}
+
+// Ring-buffer enqueue that first saves the rows it overwrites (16-byte units).
+__global__ void push_stash_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint4 *__restrict__ stash, long long n16)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        stash[i] = dst[i];
+        dst[i] = src[i];
+    }
+}
+__global__ void push_stash_bytes_kernel(char *__restrict__ dst, const char *__restrict__ src, char *__restrict__ stash, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        stash[i] = dst[i];
+        dst[i] = src[i];
+    }
+}
+
+}  // namespace mi

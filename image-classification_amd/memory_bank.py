@@ -132,8 +132,17 @@ class MemoryBank(nn.Module):
         ptr, k = self.offsets[name], self.sizes[name]
         row_bytes = bank.element_size() * (bank[0].numel() if bank.dim() > 1 else 1)
         new_ptr = ctypes.c_int64(0)
+        # a MoCo loss over this very buffer may still await its backward (moco.py:159-172 pushes
+        # first): save the rows about to be overwritten for it instead of cloning the queue
+        from .moco import protect_rows
+        stash = protect_rows(bank, ptr, min(value.shape[0], k - ptr))
         with torch.cuda.device(bank.device):
-            _lib.check(_lib.lib().mi_queue_push(bank.data_ptr(), k, row_bytes, ptr, value.data_ptr(),
-                                                value.shape[0], ctypes.byref(new_ptr), _lib.stream_ptr(bank.device)),
-                       "mi_queue_push")
+            if stash is not None:
+                _lib.check(_lib.lib().mi_queue_push_stash(bank.data_ptr(), k, row_bytes, ptr, value.data_ptr(),
+                                                          value.shape[0], stash.data_ptr(), ctypes.byref(new_ptr),
+                                                          _lib.stream_ptr(bank.device)), "mi_queue_push_stash")
+            else:
+                _lib.check(_lib.lib().mi_queue_push(bank.data_ptr(), k, row_bytes, ptr, value.data_ptr(),
+                                                    value.shape[0], ctypes.byref(new_ptr), _lib.stream_ptr(bank.device)),
+                           "mi_queue_push")
         self.offsets[name] = int(new_ptr.value)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -42,7 +42,7 @@ const char *mi_last_error(void);
  * stream it is launched on.  mi_profile_collect waits for the recorded launches of `kind`, returns
  * their summed duration (ms), count and work, and forgets them.  Process-wide debug state behind
  * a mutex; leave it off in production. */
-enum { MI_PROF_SIM = 0, MI_PROF_SELECT = 1 };
+enum { MI_PROF_SIM = 0, MI_PROF_SELECT = 1, MI_PROF_MOCO_FWD = 2, MI_PROF_MOCO_BWD = 3 };
 int mi_profile_enable(int on);
 int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *total_work);
 
@@ -121,13 +121,26 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
                 int64_t D, float temperature, float *lse, float *lpos, float *loss,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
-/* Backward w.r.t. the query only (key and queue are detached at the call site):
+/* Backward w.r.t. the query only (key and queue are detached at the call site, moco.py:153-154):
  *   dq[i] = grad_loss / (b T) * ( sum_n softmax_i[n] queue[n] + (softmax_i[pos] - 1) key_i )
- * grad_loss: device pointer to the upstream scalar gradient. */
+ * The probabilities are recomputed tile by tile from q, queue and lse (never stored).
+ * grad_loss: device pointer to the upstream scalar gradient.  D % 64 == 0, D <= 256.
+ * The reference pushes into the queue BEFORE backward (moco.py:159-172) and therefore clones the
+ * whole queue every step (moco.py:153).  Here the caller may pass the live, already pushed-into
+ * queue plus the rows the push overwrote: queue rows [patch_lo, patch_lo + patch_n) are read from
+ * patch_rows [patch_n, D] instead (patch_n == 0: no patch, patch_rows may be NULL).
+ * Workspace: mi_moco_workspace_bytes (covers forward and backward). */
 int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
                 int64_t D, float temperature, const float *lse, const float *lpos,
                 const float *grad_loss, float *dq,
+                const float *patch_rows, int64_t patch_lo, int64_t patch_n,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* mi_queue_push that first copies the rows it overwrites to stash[0 .. w) (w = rows written):
+ * the companion of mi_moco_bwd's patch.  Same truncation rule and pointer update
+ * (models/memory_bank.py:65-72). */
+int mi_queue_push_stash(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
+                        const void *value, int64_t b, void *stash, int64_t *new_ptr, mi_stream_t stream);
 
 #ifdef __cplusplus
 }
