@@ -150,34 +150,45 @@ __global__ void scatter_rows_kernel(char *__restrict__ bank, long long K, long l
     }
 }
 
-// MoCo forward, step 2: fold the per-strip (max, sumexp) partials and the positive logit.
-__global__ __launch_bounds__(64) void moco_combine_kernel(const float *q, const float *key, int D,
+// MoCo forward, step 2: fold the per-tile (max, sumexp) partials and the positive logit.
+// 256 threads = 16 rows x 16 groups; group g folds tiles g, g+16, ... of its row (16 rows of one
+// tile = one coalesced 128-byte read) and columns g*D/16.. of q.key, then the groups meet in LDS.
+__global__ __launch_bounds__(256) void moco_combine_kernel(const float *q, const float *key, int b, int D,
                                                           const float2 *part, int nparts, int lse_ld,
                                                           float inv_t, float *lse, float *lpos,
                                                           float *row_loss)
 {
-    const int row = blockIdx.x, lane = threadIdx.x;
-    float d = 0.f;
-    for (int c = lane; c < D; c += 64) d = fmaf(q[(long long)row * D + c], key[(long long)row * D + c], d);
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) d += __shfl_xor(d, s, 64);
-    const float lp = d * inv_t;
-    float m = lp;
-    for (int i = lane; i < nparts; i += 64) m = fmaxf(m, part[(long long)row * lse_ld + i].x);
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-    float sum = 0.f;
-    for (int i = lane; i < nparts; i += 64) {
-        const float2 ps = part[(long long)row * lse_ld + i];
-        if (ps.y > 0.f) sum += ps.y * expf(ps.x - m);
+    __shared__ float s_m[16][17], s_s[16][17], s_d[16][17];
+    const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int row = blockIdx.x * 16 + r;
+    float m = -INFINITY, sum = 0.f, d = 0.f;
+    if (row < b) {
+        for (int i = g; i < nparts; i += 16) {
+            const float2 ps = part[(long long)i * lse_ld + row];
+            if (ps.y > 0.f) {
+                const float mn = fmaxf(m, ps.x);
+                sum = sum * expf(m - mn) + ps.y * expf(ps.x - mn);
+                m = mn;
+            }
+        }
+        for (int c = g; c < D; c += 16) d = fmaf(q[(long long)row * D + c], key[(long long)row * D + c], d);
     }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s, 64);
-    sum += expf(lp - m);
-    if (lane == 0) {
-        const float l = m + logf(sum);
+    s_m[r][g] = m;
+    s_s[r][g] = sum;
+    s_d[r][g] = d;
+    __syncthreads();
+    if (g == 0 && row < b) {
+        float dd = 0.f;
+        for (int i = 0; i < 16; ++i) dd += s_d[r][i];
+        const float lp = dd * inv_t;
+        float mm = lp;
+        for (int i = 0; i < 16; ++i) mm = fmaxf(mm, s_m[r][i]);
+        float ss = expf(lp - mm);
+        for (int i = 0; i < 16; ++i)
+            if (s_s[r][i] > 0.f) ss += s_s[r][i] * expf(s_m[r][i] - mm);
+        const float l = mm + logf(ss);
         lse[row] = l;
-        lpos[row] = d;
+        lpos[row] = dd;
         row_loss[row] = l - lp;
     }
 }
@@ -245,8 +256,18 @@ Plan make_plan(int64_t B, int64_t N, int k)
 }
 
 template <int DT, int MODE>
-hipError_t launch_sim(const mi::SimParams &p, hipStream_t s)
+hipError_t launch_sim(const mi::SimParams &p_in, hipStream_t s)
 {
+    // 32 consecutive same-XCD workgroups form one patch of (1 << qsh) query tiles x (32 >> qsh) bank
+    // tiles.  The patch is as tall as the launch has query tiles (at most 8): a launch with few
+    // query tiles (MoCo: one) must not pad patches with workgroups that only exit -- they still
+    // queue for a CU with 129 KiB of free LDS and delayed the real ones by ~100 us at C2.
+    mi::SimParams p = p_in;
+    int qsh = 3;
+    while (qsh > 0 && (1 << (qsh - 1)) >= p.qtiles) --qsh;
+    p.qsh = qsh;
+    p.pq = (int)ceil_div(p.qtiles, 1 << qsh);
+    p.pn = (int)ceil_div(p.ntiles, 32 >> qsh);
     const int patches = p.pq * p.pn;
     const int grid = (int)ceil_div(patches, 8) * 256;
     hipLaunchKernelGGL((mi::sim_kernel<DT, MODE>), dim3(grid), dim3(mi::SIM_THREADS), 0, s, p);
@@ -374,7 +395,6 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     sp.N = (int)N;
     sp.ksteps = (int)(ld * elt_bytes(dtype) / mi::KSTEP_BYTES);
     sp.qtiles = pl.qtiles;
-    sp.pq = pl.pq;
     sp.tau = tau;
     sp.cnt = cnt;
     sp.cand = cand;
@@ -395,7 +415,6 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     sp.col0 = 0;
     sp.ncols = pl.s0_cols;
     sp.ntiles = (int)ceil_div(pl.s0_cols, mi::TILE);
-    sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
     {
         ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * sp.ncols * (double)D, s);
         HIP_CHECK((launch_sim_dt<mi::MODE_DENSE>(dtype, sp, s)));
@@ -416,8 +435,7 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
         sp.col0 = (int)col;
         sp.ncols = (int)ncols;
         sp.ntiles = (int)ceil_div(ncols, mi::TILE);
-        sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
-        {
+            {
             ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)ncols * (double)D, s);
             HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
         }
@@ -523,9 +541,9 @@ MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
     MocoPlan m{};
     m.b_pad = (int)round_up(b, mi::TILE);
     m.ntiles = (int)ceil_div(K, mi::TILE);
-    m.lse_ld = m.ntiles * 4;
+    m.lse_ld = m.b_pad;
     m.off_part = 0;
-    m.off_rowloss = (size_t)round_up((int64_t)m.b_pad * m.lse_ld * 8, 256);
+    m.off_rowloss = (size_t)round_up((int64_t)m.ntiles * m.lse_ld * 8, 256);
     m.fwd_total = m.off_rowloss + (size_t)round_up((int64_t)m.b_pad * 4, 256);
     // backward: ~256 workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
     const int64_t qtiles = ceil_div(b, mi::MB_ROWS);
@@ -571,15 +589,13 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
     sp.ncols = (int)K;
     sp.qtiles = mp.b_pad / mi::TILE;
     sp.ntiles = mp.ntiles;
-    sp.pq = (int)ceil_div(sp.qtiles, mi::PATCH_Q);
-    sp.pn = (int)ceil_div(sp.ntiles, mi::PATCH_N);
     sp.inv_t = 1.0f / temperature;
     sp.lse_part = (float2 *)(ws + mp.off_part);
     sp.lse_ld = mp.lse_ld;
     float *row_loss = (float *)(ws + mp.off_rowloss);
     ProfScope ps(MI_PROF_MOCO_FWD, 2.0 * (double)b * (double)(K + 1) * (double)D, s);
     HIP_CHECK((launch_sim<mi::DT_F32, mi::MODE_LSE>(sp, s)));
-    hipLaunchKernelGGL(moco_combine_kernel, dim3((unsigned)b), dim3(64), 0, s, q, key, (int)D, sp.lse_part, mp.lse_ld, mp.lse_ld, sp.inv_t, lse, lpos, row_loss);
+    hipLaunchKernelGGL(moco_combine_kernel, dim3((unsigned)ceil_div(b, 16)), dim3(256), 0, s, q, key, (int)b, (int)D, sp.lse_part, mp.ntiles, mp.lse_ld, sp.inv_t, lse, lpos, row_loss);
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)b, loss);
     HIP_CHECK(hipGetLastError());

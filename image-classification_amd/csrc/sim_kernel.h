@@ -53,7 +53,7 @@ struct SimParams {
     int ksteps;               // padded row bytes / 128
     int col0, ncols;          // this stage covers bank rows [col0, col0 + ncols)
     int qtiles, ntiles;       // tiles in this launch
-    int pq, pn;               // patches (groups of 8 x 4 tiles)
+    int pq, pn, qsh;          // patches of (1 << qsh) query tiles x (32 >> qsh) bank tiles (set by the launcher)
     // MODE_DENSE / MODE_FILTER
     const float *tau;         // [B_pad]  (+inf on padding rows)
     unsigned *cnt;            // [B_pad]  per-row candidate count
@@ -61,9 +61,31 @@ struct SimParams {
     int cap;
     // MODE_LSE
     float inv_t;
-    float2 *lse_part;         // [B_pad, ntiles * 4] (max, sumexp) per wave column strip
+    float2 *lse_part;         // [ntiles, lse_ld] (max, sumexp) of every row over one tile; lse_ld = padded rows
     int lse_ld;
 };
+
+// all-reduce over the 16 lanes of a DPP row (= one C-tile row of the 16x16 MFMA), no LDS traffic:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    return fmaxf(v, dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v + dpp_mov<0x140>(v);
+}
 
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
@@ -80,8 +102,8 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     const int xcd = bid & 7, seq = bid >> 3;
     const int patch = (seq >> 5) * 8 + xcd, inner = seq & 31;
     if (patch >= p.pq * p.pn) return;
-    const int qt = (patch / p.pn) * PATCH_Q + (inner & 7);
-    const int nt = (patch % p.pn) * PATCH_N + (inner >> 3);
+    const int qt = ((patch / p.pn) << p.qsh) + (inner & ((1 << p.qsh) - 1));
+    const int nt = (patch % p.pn) * (32 >> p.qsh) + (inner >> p.qsh);
     if (qt >= p.qtiles || nt >= p.ntiles) return;
     const int q0 = qt * TILE;
     const int n0 = p.col0 + nt * TILE;
@@ -346,7 +368,25 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     if (base + e < (unsigned)p.cap) p.cand[row * p.cap + base + e] = llist[tid * LCAND + e];
             }
         }
-    } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over this wave's 64 columns
+    } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over the tile's 256 columns
+        // Each wave reduces its 64 columns, the 4 column strips of a row meet in LDS (the operand
+        // buffers are free after the K loop's last barrier) and the tile writes ONE contiguous
+        // [256] float2 block.  (Per-strip 8-byte stores scattered over rows shared 128-byte lines
+        // between workgroups of different XCDs: 262k partial-line writes cost 150 us at C2.)
+        float2 *lpart = (float2 *)smem;                               // [256 rows][4 strips]
+#if defined(MI_ABLATE) && (MI_ABLATE & 32)
+        {   // timing-only: no reduction work
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
+            if (sum == 12345.678f) p.lse_part[0] = make_float2(sum, sum);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -355,18 +395,29 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (col_base + j * 16 < col_end) m = fmaxf(m, acc[i][j][r] * p.inv_t);
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+                m = row16_max(m);
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (col_base + j * 16 < col_end) s += expf(acc[i][j][r] * p.inv_t - m);
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 64);
-                const int row = row_base + i * 16 + r;
-                if (lr == 0 && row < p.B)
-                    p.lse_part[(long long)row * p.lse_ld + nt * 4 + wn] = make_float2(m, s);
+                s = row16_sum(s);
+                if (lr == 0) lpart[(wm * 128 + lq * 4 + i * 16 + r) * 4 + wn] = make_float2(m, s);
             }
+        __syncthreads();
+        if (tid < TILE) {
+            float2 a[4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = lpart[tid * 4 + j];
+                m = fmaxf(m, a[j].x);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (a[j].y > 0.f) s += a[j].y * expf(a[j].x - m);
+            p.lse_part[(long long)nt * p.lse_ld + q0 + tid] = make_float2(m, s);     // lse_ld >= padded rows
+        }
     }
 }
 
