@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--temperature", type=float, default=0.1)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
-    ap.add_argument("--query-chunk", type=int, default=12544)
+    ap.add_argument("--query-chunk", type=int, default=16384)
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the query chunks alternate between")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -116,7 +117,8 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk)
+        knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk,
+                                 n_streams=args.streams)
         return knn.predict(feature, labels, C, k, T)
 
     for _ in range(args.warmup):

@@ -109,9 +109,44 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ src
     }
 }
 
-__global__ void init_state_kernel(float *tau, unsigned *cnt, int *topk_n, int B, int B_pad)
+// pack, fast path: untransposed rows, D % 8 == 0, 16-byte aligned source rows.  One thread moves 8
+// consecutive elements (two 16-byte loads; one 16-byte bf16 store or two float stores); HBM-bound.
+template <typename OutT>
+__global__ __launch_bounds__(256) void pack_rows_vec_kernel(const float *__restrict__ src, long long ld_src,
+                                                            long long rows, int D, OutT *__restrict__ dst,
+                                                            long long ld_dst)
+{
+    const long long per_row = ld_dst >> 3;
+    const long long total = rows * per_row;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const long long r = e / per_row;
+        const int c = (int)(e - r * per_row) << 3;
+        typedef __attribute__((ext_vector_type(4))) float f4;
+        f4 a = f4{0.f, 0.f, 0.f, 0.f}, b = a;
+        if (c < D) {
+            const f4 *sp = (const f4 *)(src + r * ld_src + c);
+            a = __builtin_nontemporal_load(sp);
+            b = __builtin_nontemporal_load(sp + 1);
+        }
+        if constexpr (sizeof(OutT) == 2) {
+            typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+            bf16x8_t o;
+            o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+            o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+            *(bf16x8_t *)(dst + r * ld_dst + c) = o;
+        } else {
+            f4 *dp = (f4 *)(dst + r * ld_dst + c);
+            dp[0] = a;
+            dp[1] = b;
+        }
+    }
+}
+
+__global__ void init_state_kernel(float *tau, unsigned *cnt, int *topk_n, unsigned *big_cnt, int B, int B_pad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * mi::BIG_SUBLISTS) big_cnt[i * 32] = 0u;
     if (i < B_pad) {
         tau[i] = i < B ? -INFINITY : INFINITY;
         cnt[i] = 0u;
@@ -209,50 +244,69 @@ __global__ __launch_bounds__(256) void mean_kernel(const float *x, int n, float 
 
 // --------------------------------------------------------------------------- top-k plan
 struct Plan {
-    int B_pad, qtiles, pq;
+    int B_pad, qtiles;
     int s0_cols;        // dense bootstrap stage
-    int pn_stage;       // bank-tile patches per filter stage
-    int stage_cols;     // bank rows per filter stage
+    int min_cols;       // smallest useful filter stage (enough workgroups to fill the chip)
     int cap;            // candidate slots per row (>= every stage's columns: overflow impossible)
-    size_t off_tau, off_cnt, off_topkn, off_topk, off_cand, total;
+    size_t off_tau, off_cnt, off_topkn, off_big, off_topk, off_cand, fixed, total;
 };
 
 constexpr int S0_COLS = 2048;
-constexpr int64_t CAND_BUDGET_BYTES = 4ll << 30;   // soft cap of the candidate buffer
+constexpr int BIG_CNT_BYTES = 2 * mi::BIG_SUBLISTS * 128;      // one 128-byte line per counter
+// rows (row >> 2) % 64 == s go to sub-list s: at most 4 * ceil(B_pad / 256) of them
+inline int big_stride(int B_pad) { return 4 * (int)ceil_div(B_pad, 4 * mi::BIG_SUBLISTS); }
+constexpr int STAGE_QUANTUM = 1024;                // filter stages are whole multiples of 4 bank tiles
+constexpr int64_t CAND_BUDGET_BYTES = 8ll << 30;   // default size of the candidate buffer
 
-Plan make_plan(int64_t B, int64_t N, int k)
+// Workspace layout.  cand_bytes < 0: the default candidate budget; otherwise what the caller gave.
+Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row_bytes = 0)
 {
     Plan pl{};
     pl.B_pad = (int)round_up(B, mi::TILE);
     pl.qtiles = pl.B_pad / mi::TILE;
-    pl.pq = (int)ceil_div(pl.qtiles, mi::PATCH_Q);
     pl.s0_cols = (int)(N < S0_COLS ? N : S0_COLS);
-    // Filter stage size.  Larger stages mean fewer launches, a shorter tail per launch and fewer
-    // threshold-refresh (select) passes; the price is the worst-case candidate buffer
-    // (B_pad x stage columns x 8 B), so grow the stage up to a memory budget.  Lower bound: enough
-    // patches for >= 3 rounds on every XCD; always a multiple of 8 patches when possible so the 8 XCDs
-    // finish together; never more columns than remain.
-    const int step = 8 / gcd(pl.pq, 8);
-    int pn = (int)round_up(ceil_div(24, pl.pq), step);
-    const int64_t budget_cols = CAND_BUDGET_BYTES / ((int64_t)pl.B_pad * 8);
-    const int pn_budget = (int)(budget_cols / (mi::PATCH_N * mi::TILE)) / step * step;
-    if (pn_budget > pn) pn = pn_budget;
-    const int64_t remaining = N - pl.s0_cols;
-    const int64_t need = ceil_div(remaining > 0 ? remaining : 1, (int64_t)mi::PATCH_N * mi::TILE);
-    if (pn > need) pn = (int)need;
-    if (pn < 1) pn = 1;
-    pl.pn_stage = pn;
-    pl.stage_cols = pn * mi::PATCH_N * mi::TILE;
-    pl.cap = pl.stage_cols > S0_COLS ? pl.stage_cols : S0_COLS;
+    pl.min_cols = (int)round_up(ceil_div(768, pl.qtiles) * mi::TILE, STAGE_QUANTUM);
+    const int64_t row_bytes = (int64_t)pl.B_pad * 8;
+    int64_t cap = (cand_bytes < 0 ? CAND_BUDGET_BYTES : cand_bytes) / row_bytes / STAGE_QUANTUM * STAGE_QUANTUM;
+    int64_t useful = round_up(N > S0_COLS ? N - S0_COLS : S0_COLS, STAGE_QUANTUM);        // one stage for all the rest
+    if (useful < S0_COLS) useful = S0_COLS;
+    if (cap > useful) cap = useful;
+    // Keep one stage's bank slice (+ the query chunk) resident in the 256 MiB Infinity Cache: the
+    // slice is re-read once per group of 8 query tiles, and the K loop is latency sensitive (a
+    // 268 MB slice ran 12 % slower than a 134 MB one at C4).
+    if (bank_row_bytes > 0) {
+        int64_t fit = ((128ll << 20) / bank_row_bytes) / STAGE_QUANTUM * STAGE_QUANTUM;
+        if (fit < 8 * STAGE_QUANTUM) fit = 8 * STAGE_QUANTUM;
+        if (cap > fit) cap = fit;
+    }
+    if (cap < S0_COLS) cap = cand_bytes < 0 ? S0_COLS : 0;      // 0: the caller's workspace is too small
+    pl.cap = (int)cap;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (size_t)round_up((int64_t)(off + bytes), 256); return o; };
     pl.off_tau = take((size_t)pl.B_pad * 4);
     pl.off_cnt = take((size_t)pl.B_pad * 4);
     pl.off_topkn = take((size_t)pl.B_pad * 4);
+    pl.off_big = take((size_t)BIG_CNT_BYTES + (size_t)mi::BIG_SUBLISTS * big_stride(pl.B_pad) * 4);   // counters + row sub-lists
     pl.off_topk = take((size_t)pl.B_pad * k * 8);
+    pl.fixed = off;
     pl.off_cand = take((size_t)pl.B_pad * pl.cap * 8);
     pl.total = off;
     return pl;
+}
+
+// Filter stage schedule.  A stage filters with the threshold tau known at its start (the k-th best
+// of the `seen` columns before it), so about k * ln(1 + n / seen) elements per row pass it: stages
+// grow geometrically (n = seen) -- ~k ln 2 survivors per row and stage, O(log N) threshold
+// refreshes -- until the candidate buffer (worst case: every element passes) or the cache-fit
+// limit caps them.  Growth factor 4 (n = 3 * seen): small launches run well below the large ones'
+// rate, so the ramp is kept short at the price of ~3k instead of ~k candidates in its stages.
+int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t N)
+{
+    int64_t n = 3 * seen / STAGE_QUANTUM * STAGE_QUANTUM;
+    if (n < pl.min_cols) n = pl.min_cols;
+    if (n > pl.cap) n = pl.cap;
+    if (n > N - seen) n = N - seen;
+    return n;
 }
 
 template <int DT, int MODE>
@@ -340,6 +394,14 @@ int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows,
     if (D > INT32_MAX / 2 || ld_dst > INT32_MAX / 2) return fail(MI_ERR_ARG, "mi_pack_rows: D too large");
     hipStream_t s = (hipStream_t)stream;
     if (rows > (int64_t)INT32_MAX * 16 || ld_dst > 65535 * 32) return fail(MI_ERR_ARG, "mi_pack_rows: shape too large");
+    if (!transposed && D % 8 == 0 && ld_dst % 8 == 0 && ld_src % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const long long items = rows * (ld_dst / 8);
+        const unsigned vgrid = (unsigned)(ceil_div(items, 256) < 256 * 64 ? ceil_div(items, 256) : 256 * 64);
+        if (dtype == MI_BF16) hipLaunchKernelGGL((pack_rows_vec_kernel<__bf16>), dim3(vgrid), dim3(256), 0, s, src, ld_src, rows, (int)D, (__bf16 *)dst, ld_dst);
+        else hipLaunchKernelGGL((pack_rows_vec_kernel<float>), dim3(vgrid), dim3(256), 0, s, src, ld_src, rows, (int)D, (float *)dst, ld_dst);
+        HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
     dim3 grid((unsigned)ceil_div(rows, 32), (unsigned)ceil_div(ld_dst, 32));
     if (dtype == MI_BF16) {
         if (transposed) hipLaunchKernelGGL((pack_kernel<__bf16, true>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (__bf16 *)dst, ld_dst);
@@ -355,7 +417,7 @@ int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows,
 size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k)
 {
     if (B <= 0 || N <= 0 || k <= 0 || k > MI_MAX_K || B > (1 << 30) || N > INT32_MAX - 2 * mi::TILE) return 0;
-    return make_plan(B, N, k).total;
+    return make_plan(B, N, k, -1).total;
 }
 
 int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
@@ -372,8 +434,12 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     const int64_t ld = mi_knn_ld(D, dtype);
     if (ldq != ld || ldb != ld) return fail(MI_ERR_ARG, "mi_knn_topk: ldq/ldb must equal mi_knn_ld(D)=%lld (got %lld, %lld)", (long long)ld, (long long)ldq, (long long)ldb);
     if (((uintptr_t)q | (uintptr_t)bank | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_knn_topk: q, bank and workspace must be 16-byte aligned");
-    const Plan pl = make_plan(B, N, k);
-    if (workspace_bytes < pl.total) return fail(MI_ERR_WORKSPACE, "mi_knn_topk: workspace %zu < required %zu", workspace_bytes, pl.total);
+    // the stage size follows the workspace the caller actually gave (more memory = fewer, larger stages)
+    const size_t fixed = make_plan(B, N, k, -1).fixed;
+    const Plan pl = make_plan(B, N, k, workspace_bytes > fixed ? (int64_t)(workspace_bytes - fixed) : 0, ld * elt_bytes(dtype));
+    if (pl.cap == 0 || workspace_bytes < pl.total)
+        return fail(MI_ERR_WORKSPACE, "mi_knn_topk: workspace %zu is below the minimum %zu (recommended: mi_knn_topk_workspace_bytes)",
+                    workspace_bytes, fixed + (size_t)pl.B_pad * S0_COLS * 8);
 
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
@@ -383,7 +449,9 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     unsigned long long *topk = (unsigned long long *)(ws + pl.off_topk);
     uint2 *cand = (uint2 *)(ws + pl.off_cand);
 
-    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, cnt, topk_n, (int)B, pl.B_pad);
+    unsigned *big_cnt = (unsigned *)(ws + pl.off_big);
+    int *big_rows = (int *)(ws + pl.off_big + BIG_CNT_BYTES);
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, cnt, topk_n, big_cnt, (int)B, pl.B_pad);
     HIP_CHECK(hipGetLastError());
 
     mi::SimParams sp{};
@@ -430,12 +498,16 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     }
 
     // filter stages
-    while (col < N) {
-        const int64_t ncols = (N - col) < pl.stage_cols ? (N - col) : pl.stage_cols;
+    sel.big_rows = big_rows;
+    sel.big_cnt = big_cnt;
+    sel.big_stride = big_stride(pl.B_pad);
+    for (int stage = 0; col < N; ++stage) {
+        sel.parity = stage & 1;
+        const int64_t ncols = next_stage_cols(pl, col, N);
         sp.col0 = (int)col;
         sp.ncols = (int)ncols;
         sp.ntiles = (int)ceil_div(ncols, mi::TILE);
-            {
+        {
             ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)ncols * (double)D, s);
             HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
         }
@@ -450,7 +522,7 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
             else if (k <= 512) hipLaunchKernelGGL((mi::merge_kernel<8>), mgrid, dim3(256), 0, s, sel);
             else hipLaunchKernelGGL((mi::merge_kernel<16>), mgrid, dim3(256), 0, s, sel);
             HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
+            hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3(2048), dim3(mi::SEL_THREADS), 0, s, sel);
             HIP_CHECK(hipGetLastError());
         }
     }

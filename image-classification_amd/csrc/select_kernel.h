@@ -52,6 +52,7 @@ __device__ __forceinline__ void bitonic_sort_desc(unsigned long long *keys, int 
     }
 }
 
+constexpr int BIG_SUBLISTS = 64;
 constexpr int MERGE_MAX_NEW = 64;     // rows with <= 64 new candidates take the wave-per-row merge path
 
 struct SelectParams {
@@ -74,14 +75,19 @@ struct SelectParams {
     long long *out_idx;         // [B, k]
     long long idx_base;
     int skip_small;             // SRC_LIST: rows with <= MERGE_MAX_NEW candidates were merged by merge_kernel
+    // SRC_LIST work list: merge_kernel appends the rows it leaves to select_kernel (> MERGE_MAX_NEW
+    // candidates) to big_rows and counts them in big_cnt[parity]; select_kernel<SRC_LIST> then runs a
+    // fixed grid over that list instead of one (mostly idle) workgroup per query row.
+    int *big_rows;              // [BIG_SUBLISTS][big_stride]
+    unsigned *big_cnt;          // [2][BIG_SUBLISTS] counters, one per 128-byte line, alternating by stage;
+                                // merge_kernel zeroes the other set
+    int big_stride;             // >= rows one sub-list can receive
+    int parity;
 };
 
 template <int SRC>
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams p)
+__device__ __forceinline__ void select_row(const SelectParams &p, const int row, unsigned long long *keys, int &s_valid)
 {
-    __shared__ unsigned long long keys[SORT_P];
-    __shared__ int s_valid;
-    const int row = blockIdx.x;
     const int tid = threadIdx.x;
 
     int n_new;
@@ -163,6 +169,26 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams 
     }
 }
 
+template <int SRC>
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams p)
+{
+    __shared__ unsigned long long keys[SORT_P];
+    __shared__ int s_valid;
+    if constexpr (SRC == SRC_LIST) {
+        if (p.big_rows) {
+            // workgroup b serves sub-list b % BIG_SUBLISTS, every (gridDim / BIG_SUBLISTS)-th entry
+            const unsigned sub = blockIdx.x & (BIG_SUBLISTS - 1), per = gridDim.x / BIG_SUBLISTS;
+            const unsigned n = p.big_cnt[(p.parity * BIG_SUBLISTS + sub) * 32];
+            for (unsigned i = blockIdx.x / BIG_SUBLISTS; i < n; i += per) {
+                select_row<SRC>(p, p.big_rows[(long long)sub * p.big_stride + i], keys, s_valid);
+                __syncthreads();                                   // keys / s_valid are reused by the next row
+            }
+            return;
+        }
+    }
+    select_row<SRC>(p, blockIdx.x, keys, s_valid);
+}
+
 // Wave-per-row merge: the common case after the first few stages is a handful of new candidates
 // per row.  One wave holds the row's sorted top-k in registers (KPL keys per lane, key i on lane
 // i % 64) and its <= 64 new candidates one per lane, and computes every key's position in the
@@ -179,7 +205,19 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
     if (row >= p.B) return;
     const unsigned c = p.cnt[row];
     const bool finalize = p.out_val != nullptr;
-    if (c > (unsigned)MERGE_MAX_NEW || (c == 0 && !finalize)) return;
+    if (blockIdx.x == 0 && threadIdx.x < BIG_SUBLISTS && p.big_cnt)
+        p.big_cnt[((p.parity ^ 1) * BIG_SUBLISTS + threadIdx.x) * 32] = 0u;                  // the next stage's counters
+    if (c > (unsigned)MERGE_MAX_NEW) {
+        // one returning atomic per row on one word saturates at ~88 per us (16384 rows: 187 us);
+        // the rows are spread over 64 sub-lists instead, each with its own counter line
+        if (lane == 0 && p.big_rows) {
+            const unsigned sub = (unsigned)(row >> 2) & (BIG_SUBLISTS - 1);
+            const unsigned slot = atomicAdd(p.big_cnt + (p.parity * BIG_SUBLISTS + sub) * 32, 1u);
+            p.big_rows[(long long)sub * p.big_stride + slot] = (int)row;
+        }
+        return;
+    }
+    if (c == 0 && !finalize) return;
     const int n_new = (int)c;
     const int k = p.k;
     const int n_cur = p.topk_n[row];

@@ -22,6 +22,7 @@ gloo; the default ops are the HIP kernels and fail loudly without the library or
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional, Tuple
 
 import torch
@@ -69,7 +70,7 @@ class ShardedKnn:
     """
 
     def __init__(self, bank_rows_local: torch.Tensor, idx_base: int, group=None, ops=None,
-                 compute_dtype=None, query_chunk: int = 8192):
+                 compute_dtype=None, query_chunk: int = 8192, n_streams: int = 1):
         self.group = group
         self.world = dist.get_world_size(group) if _dist_on() else 1
         self.rank = dist.get_rank(group) if _dist_on() else 0
@@ -78,6 +79,7 @@ class ShardedKnn:
         self.bank = self.ops.build_bank(bank_rows_local, self.idx_base)
         self.n_local = int(self.ops.bank_rows(self.bank))
         self.query_chunk = int(query_chunk)
+        self.n_streams = max(1, int(n_streams))
         sizes = [self.n_local]
         if self.world > 1:
             t = torch.tensor([self.n_local], dtype=torch.int64, device=bank_rows_local.device)
@@ -121,24 +123,41 @@ class ShardedKnn:
 
     @torch.no_grad()
     def topk(self, feature: torch.Tensor, k: int):
-        """Global top-k (values, global rows) for every query, identical on every rank."""
+        """Global top-k (values, global rows) for every query, identical on every rank.
+
+        Query chunks alternate between ``n_streams`` HIP streams: the threshold-refresh kernels,
+        launch tails, exchange and merge of one chunk run beside the next chunk's GEMM."""
         if k > self.n_total:
             raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
-        outs_v, outs_i = [], []
-        pending = None
         B = feature.shape[0]
-        for s in range(0, B, self.query_chunk):
-            val, idx = self._local_candidates(feature[s:s + self.query_chunk], k)
-            nxt = self._exchange(val, idx)           # chunk s's all-gather runs beside the next chunk's GEMM
+        starts = list(range(0, B, self.query_chunk))
+        side = _side_streams(feature.device, self.n_streams) if (feature.is_cuda and len(starts) > 1) else None
+        main = torch.cuda.current_stream(feature.device) if side else None
+        outs = [None] * len(starts)
+        pending = None                                   # (chunk number, exchange in flight)
+
+        def on_stream(i):
+            return torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()
+
+        for i, s in enumerate(starts):
+            if side and i < len(side):
+                side[i].wait_stream(main)                # inputs were produced on the caller's stream
+            with on_stream(i):
+                val, idx = self._local_candidates(feature[s:s + self.query_chunk], k)
+                nxt = self._exchange(val, idx)           # chunk i's all-gather runs beside the next chunk's GEMM
             if pending is not None:
-                outs = self._finish(pending, k)
-                outs_v.append(outs[0])
-                outs_i.append(outs[1])
-            pending = nxt
-        outs = self._finish(pending, k)
-        outs_v.append(outs[0])
-        outs_i.append(outs[1])
-        return torch.cat(outs_v, 0), torch.cat(outs_i, 0)
+                with on_stream(pending[0]):
+                    outs[pending[0]] = self._finish(pending[1], k)
+            pending = (i, nxt)
+        with on_stream(pending[0]):
+            outs[pending[0]] = self._finish(pending[1], k)
+        if side:
+            for st in side[:len(starts)]:
+                main.wait_stream(st)
+            for v, ix in outs:
+                v.record_stream(main)
+                ix.record_stream(main)
+        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 
     def _finish(self, pending, k):
         gv, gi, works = pending
@@ -156,6 +175,17 @@ class ShardedKnn:
             raise ValueError(f"feature_labels has {feature_labels.numel()} entries for a bank of {self.n_total} rows")
         val, idx = self.topk(feature, int(knn_k))
         return self.ops.vote(val, idx, feature_labels, int(classes), float(knn_t))
+
+
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    """Side streams are created once per device and reused (creation synchronises the device)."""
+    key = (torch.device(device).index, n)
+    if key not in _SIDE:
+        _SIDE[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return _SIDE[key]
 
 
 def _dist_on() -> bool:

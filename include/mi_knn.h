@@ -58,7 +58,11 @@ int64_t mi_knn_ld(int64_t D, int dtype);
 int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows, int64_t D,
                  int dtype, void *dst, int64_t ld_dst, mi_stream_t stream);
 
-/* Workspace (bytes) for mi_knn_topk. */
+/* Recommended workspace (bytes) for mi_knn_topk: fixed per-row state plus a candidate buffer of
+ * up to 8 GiB.  mi_knn_topk sizes its filter stages by the workspace it is actually given: the
+ * candidate buffer holds the worst case of one stage (every similarity of the stage passing), so a
+ * larger workspace means fewer, larger stages; the minimum is the fixed part + B_pad*2048*8 bytes
+ * (B_pad = B rounded up to 256).  The result never depends on the workspace size. */
 size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k);
 
 /* Fused similarity GEMM + streaming per-row top-k.  Replaces models/knn.py:6 (torch.mm) and

@@ -193,6 +193,20 @@ def test_index_base_and_merge_equals_unsharded(ica):
         assert np.array_equal(v.cpu().numpy(), vo) and np.array_equal(i.cpu().numpy(), io)
 
 
+@pytest.mark.parametrize("streams", [1, 2, 3])
+def test_chunked_multi_stream_driver_equals_single_call(ica, streams):
+    """ShardedKnn (world 1): query chunks alternating between side streams give the single-call result bit for bit."""
+    f, x, lab = _rand_case(1100, 12000, 64, 10, 21)
+    k = 200
+    v_ref, i_ref = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "bf16"), k)
+    knn = ica.sharded.ShardedKnn(dev(x), 0, compute_dtype="bf16", query_chunk=256, n_streams=streams)
+    v, i = knn.topk(dev(f), k)
+    assert torch.equal(v, v_ref) and torch.equal(i, i_ref)
+    pred = knn.predict(dev(f), dev(lab), 10, k, 0.1)
+    ref = ica.knn_predict(dev(f), ica.BankIndex.from_rows(dev(x), "bf16"), dev(lab), 10, k, 0.1)
+    assert torch.equal(pred, ref)
+
+
 @pytest.mark.parametrize("C,k", [(1, 5), (10, 200), (1000, 200), (5000, 64), (65536, 33)])
 def test_vote_kernel_vs_oracle(ica, C, k):
     rs = np.random.RandomState(C + k)
