@@ -89,6 +89,9 @@ __device__ __forceinline__ float row16_sum(float v)
 
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
+#ifndef MI_DMA_SHIFT
+#define MI_DMA_SHIFT 0
+#endif
 
 template <int DT, int MODE>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
@@ -142,6 +145,31 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         const unsigned base = (unsigned)(size_t)(AS3 char *)(smem + buf * STAGE_BYTES + w * 4096 + i * 1024);
         const long long koff = (long long)t * KSTEP_BYTES;
         unsigned keep;
+#if defined(MI_ABLATE) && (MI_ABLATE & 64)
+        {   // timing-only: the DMA instructions issue with EXEC = 0 (no memory traffic at all)
+            unsigned long long ex;
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\ts_mov_b64 %[ex], exec\n\ts_mov_b64 exec, 0\n\t"
+                "s_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a], off\n\t"
+                "s_mov_b32 m0, %[lb]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b], off\n\t"
+                "s_mov_b32 m0, %[keep]\n\ts_mov_b64 exec, %[ex]"
+                : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                : [la] "s"(base), [lb] "s"(base + OPERAND_TILE_BYTES), [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
+                : "memory");
+            return;
+        }
+#endif
+#if defined(MI_ABLATE) && (MI_ABLATE & 128)
+        {   // timing-only: same global traffic, but into (discarded) registers instead of LDS
+            f32x4 d0, d1;
+            asm volatile(
+                "global_load_dwordx4 %[d0], %[a], off\n\tglobal_load_dwordx4 %[d1], %[b], off"
+                : [d0] "=&v"(d0), [d1] "=&v"(d1)
+                : [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
+                : "memory");
+            return;
+        }
+#endif
         asm volatile(
             "s_mov_b32 %[keep], m0\n\t"
             "s_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a], off\n\t"
@@ -151,7 +179,11 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             : [la] "s"(base), [lb] "s"(base + OPERAND_TILE_BYTES), [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
             : "memory");
     };
+#if defined(MI_ABLATE) && (MI_ABLATE & 16)
+    auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); };   // timing-only: one K-step of DMA stays in flight
+#else
     auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#endif
 
     // ---- MFMA operand read offsets.  Lane reads row (lane & 15) of a 16-row block; K chunk
     // (lane >> 4) [+4 for the second half of the K-step]; swizzle term depends on the lane only.
@@ -195,7 +227,13 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 bf16x8 *ac = (pr & 1) ? a1 : a0, *an = (pr & 1) ? a0 : a1;
                 bf16x8 *bc = s ? b1 : b0;
                 if constexpr (DMA) {
+#if MI_DMA_SHIFT == 0
                     if (pr < 4) stage_pair(pr, t + 1, nbuf);
+#else
+                    // the two waves of a SIMD (w, w + 4) issue their pieces MI_DMA_SHIFT groups apart
+                    if (pr < 4) { if (w < 4) stage_pair(pr, t + 1, nbuf); }
+                    if (pr >= MI_DMA_SHIFT && pr < MI_DMA_SHIFT + 4) { if (w >= 4) stage_pair(pr - MI_DMA_SHIFT, t + 1, nbuf); }
+#endif
                 }
                 if (pr < 7) {
                     const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;

@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection CSVs: per kernel (name prefix), mean of each counter per dispatch."""
+"""Summarise rocprofv3 --pmc counter_collection CSVs: for kernels whose name contains <needle>, restricted to the
+dispatches with the largest grid (the full-size filter stages), the mean of each counter per dispatch."""
 import csv
 import glob
 import sys
 from collections import defaultdict
 
+csv.field_size_limit(1 << 30)
+
 
 def main(root, needle):
-    acc = defaultdict(list)
+    rows = []
     for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
             if needle in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                rows.append((int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+    if not rows:
+        print("no dispatches matched")
+        return
+    big = max(g for g, _, _ in rows)
+    acc = defaultdict(list)
+    for g, n, v in rows:
+        if g == big:
+            acc[n].append(v)
+    print(f"# grid {big} ({big // 512} workgroups), per-dispatch means")
     for k in sorted(acc):
         v = acc[k]
         print(f"{k},{len(v)},{sum(v) / len(v):.6g}")
