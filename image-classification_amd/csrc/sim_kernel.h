@@ -238,11 +238,23 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 if (pr < 7) {
                     const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;
                     const int co = ns ? coff1 : coff0;
+#if defined(MI_ABLATE) && (MI_ABLATE & 256)
+                    if (ns) {                           // timing-only: half the operand reads (K-half 1 reuses registers)
+                        an[0] = ac[1];
+                        an[1] = ac[0];
+                        if (pr == 3) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) b1[j] = b0[3 - j];
+                        }
+                    } else
+#endif
+                    {
                     an[0] = *(const bf16x8 *)(la + (2 * np) * 2048 + co);
                     an[1] = *(const bf16x8 *)(la + (2 * np + 1) * 2048 + co);
                     if (pr == 3) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) b1[j] = *(const bf16x8 *)(lb + j * 2048 + coff1);
+                    }
                     }
                 }
 #pragma unroll
@@ -395,6 +407,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     }
                 }
             }
+#if defined(MI_ABLATE) && (MI_ABLATE & 1024)
+        return;                                                     // timing-only: no flush of the LDS lists
+#endif
         __syncthreads();
         if (tid < TILE) {
             unsigned n = lcnt[tid];
