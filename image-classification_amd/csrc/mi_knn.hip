@@ -251,7 +251,10 @@ struct Plan {
     size_t off_tau, off_cnt, off_topkn, off_big, off_topk, off_cand, fixed, total;
 };
 
-constexpr int S0_COLS = 2048;
+#ifndef MI_S0_COLS
+#define MI_S0_COLS 2048
+#endif
+constexpr int S0_COLS = MI_S0_COLS;     // dense bootstrap columns
 constexpr int BIG_CNT_BYTES = 2 * mi::BIG_SUBLISTS * 128;      // one 128-byte line per counter
 // rows (row >> 2) % 64 == s go to sub-list s: at most 4 * ceil(B_pad / 256) of them
 inline int big_stride(int B_pad) { return 4 * (int)ceil_div(B_pad, 4 * mi::BIG_SUBLISTS); }

@@ -7,11 +7,14 @@ this module is the scale-out the north star asks for and has no reference counte
   * queries are replicated (as the reference's ``StorageBank`` already leaves them on every rank);
   * every rank runs the fused similarity + top-k over ITS shard, producing ``(score, global row)``
     candidates ``[B, k]``;
-  * ONE exchange step: an all-gather of the candidates (``ncclAllGather`` through
-    ``torch.distributed``; 8 bytes x k per query and rank -- 10^2..10^3 x smaller than the bank
-    traffic), issued per query chunk so that chunk i's exchange overlaps chunk i+1's GEMM;
-  * a deterministic merge by (score desc, global row asc) and the vote, replicated on every rank,
-    so each rank ends with the same ``LongTensor[B, classes]`` the reference would return.
+  * ONE exchange step per query chunk, issued asynchronously so that chunk i's exchange overlaps
+    chunk i+1's GEMM (payload: 8 bytes x k per query and rank -- 10^2..10^3 x smaller than the
+    bank traffic).  ``predict`` uses the all-to-all shape (``ncclSend/Recv`` groups through
+    ``torch.distributed.all_to_all_single``): rank j receives the candidates of ITS slice of the
+    chunk's queries from every rank, merges and votes them once; ``topk`` uses the all-gather
+    shape (``ncclAllGather``) and leaves the full top-k on every rank;
+  * a deterministic merge by (score desc, global row asc), then the vote; the rankings (or only
+    their top-1 column, which is all the caller consumes) are all-gathered at the end.
 
 Because each dot product is computed identically wherever its bank row lives and the merge order
 is total, the result is bit-identical for every G (tests: GPU ``test_index_base_and_merge_*`` and
@@ -167,14 +170,103 @@ class ShardedKnn:
             return gv[0], gi[0]
         return self.ops.merge(gv, gi, k)
 
+    # -- query-sliced exchange (predict) ------------------------------------------------------
+    def _to_owners(self, val: torch.Tensor, idx: torch.Tensor):
+        """ONE exchange step, all-to-all shaped: rank j receives, from every rank, the candidates of
+        ITS slice of the chunk's queries (``shard_bounds(c, G, j)``), so merge and vote are done once
+        per query instead of once per query and rank, and each rank receives c/G x G x k candidates
+        instead of c x G x k.  Payload: (float32 score bits, int32 global row) in one int32 tensor.
+        Returns (buffer [G, c_j, 2, k] int32, pending work or None)."""
+        G, c, k = self.world, val.shape[0], val.shape[1]
+        lo, hi = shard_bounds(c, G, self.rank)
+        send = torch.stack((val.contiguous().view(torch.int32), idx.to(torch.int32)), dim=1)        # [c, 2, k]
+        if G == 1:
+            return send[None], None
+        if dist.get_backend(self.group) == "nccl":
+            sizes = [shard_bounds(c, G, j)[1] - shard_bounds(c, G, j)[0] for j in range(G)]
+            recv = torch.empty((G * (hi - lo), 2, k), dtype=torch.int32, device=val.device)
+            work = dist.all_to_all_single(recv, send, output_split_sizes=[hi - lo] * G, input_split_sizes=sizes,
+                                          group=self.group, async_op=True)
+            return recv.view(G, hi - lo, 2, k), work
+        # any other backend (gloo in the tests): all-gather through host memory, keep the own slice
+        host = send.cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(G)]
+        dist.all_gather(parts, host, group=self.group)
+        return torch.stack([p[lo:hi] for p in parts]).to(val.device), None
+
+    def _own_slice(self, pending, k, feature_labels, classes, knn_t):
+        buf, work = pending
+        if work is not None:
+            work.wait()
+        if buf.shape[1] == 0:
+            return torch.empty((0, classes), dtype=torch.int64, device=buf.device)
+        val = buf[:, :, 0, :].contiguous().view(torch.float32)
+        idx = buf[:, :, 1, :].to(torch.int64)
+        if self.world > 1:
+            val, idx = self.ops.merge(val, idx, k)
+        else:
+            val, idx = val[0], idx[0]
+        return self.ops.vote(val, idx, feature_labels, classes, knn_t)
+
     @torch.no_grad()
-    def predict(self, feature, feature_labels, classes, knn_k, knn_t):
-        """Same result contract as ``knn_predict``: LongTensor[B, classes] on every rank.
-        ``feature_labels`` is the FULL [N] label vector (replicated, as in the reference)."""
+    def predict(self, feature, feature_labels, classes, knn_k, knn_t, gather: str = "full"):
+        """The kNN monitor over the sharded bank.  ``feature_labels`` is the FULL [N] label vector
+        (replicated, as in the reference).
+
+        gather="full": the reference's result contract on every rank -- LongTensor[B, classes]
+                       (the ranking slices are all-gathered: B x classes x 8 bytes per rank).
+        gather="top1": LongTensor[B] of the top-1 class per query on every rank -- the only column the
+                       caller consumes (``ssltrainer.py:187``); the full rankings stay with the rank
+                       that owns the query slice (``self.local_rows``, ``self.local_ranking``)."""
+        if gather not in ("full", "top1"):
+            raise ValueError("gather must be 'full' or 'top1'")
         if feature_labels.numel() != self.n_total:
             raise ValueError(f"feature_labels has {feature_labels.numel()} entries for a bank of {self.n_total} rows")
-        val, idx = self.topk(feature, int(knn_k))
-        return self.ops.vote(val, idx, feature_labels, int(classes), float(knn_t))
+        k, classes, knn_t = int(knn_k), int(classes), float(knn_t)
+        if k > self.n_total:
+            raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
+        if self.n_total >= 2 ** 31:
+            raise ValueError("the candidate exchange carries int32 global rows: N must be < 2^31")
+        B, G = feature.shape[0], self.world
+        starts = list(range(0, B, self.query_chunk))
+        slices, rows = [], []
+        pending = None
+        for s in starts:
+            f = feature[s:s + self.query_chunk]
+            val, idx = self._local_candidates(f, k)
+            nxt = self._to_owners(val, idx)              # chunk s's exchange runs beside the next chunk's GEMM
+            if pending is not None:
+                slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
+            pending = nxt
+            lo, hi = shard_bounds(f.shape[0], G, self.rank)
+            rows.append(torch.arange(s + lo, s + hi, device=feature.device))
+        slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
+        self.local_rows = torch.cat(rows)
+        self.local_ranking = torch.cat(slices, 0)
+        if G == 1:
+            return self.local_ranking if gather == "full" else self.local_ranking[:, 0].contiguous()
+        # final gather: pad every rank's slice to the same length, then undo the (chunk, owner) interleave
+        mine = self.local_ranking if gather == "full" else self.local_ranking[:, :1]
+        width = mine.shape[1]
+        per_chunk = [[shard_bounds(min(self.query_chunk, B - s), G, j) for j in range(G)] for s in starts]
+        longest = max(sum(hi - lo for lo, hi in (pc[j] for pc in per_chunk)) for j in range(G))
+        padded = torch.zeros((longest, width), dtype=torch.int64, device=mine.device)
+        padded[:mine.shape[0]] = mine
+        if dist.get_backend(self.group) == "nccl":
+            allr = torch.empty((G * longest, width), dtype=torch.int64, device=mine.device)
+            dist.all_gather_into_tensor(allr, padded, group=self.group)
+            allr = allr.view(G, longest, width)
+        else:
+            parts = [torch.empty_like(padded.cpu()) for _ in range(G)]
+            dist.all_gather(parts, padded.cpu(), group=self.group)
+            allr = torch.stack(parts).to(mine.device)
+        out = torch.empty((B, width), dtype=torch.int64, device=mine.device)
+        offs = [0] * G
+        for s, pc in zip(starts, per_chunk):
+            for j, (lo, hi) in enumerate(pc):
+                out[s + lo:s + hi] = allr[j, offs[j]:offs[j] + (hi - lo)]
+                offs[j] += hi - lo
+        return out if gather == "full" else out[:, 0].contiguous()
 
 
 _SIDE = {}

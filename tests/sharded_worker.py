@@ -64,8 +64,10 @@ def main(rank, world, port, use_gpu, out_dir):
         assert knn.n_total == x.shape[0] and knn.shard_sizes[rank] == hi - lo
         val, idx = knn.topk(torch.from_numpy(f).to(dev), k)
         pred = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T)
+        top1 = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T, gather="top1")
+        assert torch.equal(knn.local_ranking, pred[knn.local_rows])     # the owner's slices are the full result's rows
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), val=val.cpu().numpy(), idx=idx.cpu().numpy(),
-                 pred=pred.cpu().numpy())
+                 pred=pred.cpu().numpy(), top1=top1.cpu().numpy(), local_rows=knn.local_rows.cpu().numpy())
         # MemoryBank.push all-gathers the keys of every rank first (memory_bank.py:64)
         if use_gpu:
             mb = ica.MemoryBank()

@@ -52,6 +52,9 @@ def _check(outs, ref, exact_values):
             assert np.allclose(o["val"], ref["sim_weight"], atol=1e-5)
         assert np.array_equal(o["pred"][:, 0], ref["pred_labels"][:, 0])
         assert np.array_equal(o["pred"], outs[0]["pred"])           # identical on every rank
+        assert np.array_equal(o["top1"], o["pred"][:, 0])
+    owned = np.sort(np.concatenate([o["local_rows"] for o in outs]))
+    assert np.array_equal(owned, np.arange(outs[0]["pred"].shape[0]))   # every query has exactly one owner
 
 
 def test_shard_bounds_cover_everything():
