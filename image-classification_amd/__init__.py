@@ -5,9 +5,9 @@ One hot path of sailist/image-classification, rebuilt for gfx950: the weighted-k
 Import as ``image_classification_amd`` (alias module at the repository root)."""
 from . import _lib
 from . import sharded
-from .knn import BankIndex, knn_merge, knn_predict, knn_predict_full, knn_topk, knn_vote, pack_rows
+from .knn import BankBuilder, BankIndex, knn_merge, knn_predict, knn_predict_full, knn_topk, knn_vote, pack_rows
 from .memory_bank import MemoryBank, StorageBank
 from .moco import contrastive_loss2, moco_queue_loss
 
-__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex",
+__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
            "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "sharded", "_lib"]

@@ -143,6 +143,26 @@ __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const float *__restr
     }
 }
 
+// bank construction (ssltrainer.py:172-179): L2-normalise each row and write it straight into the packed
+// [N, ld] bank in the compute dtype.  One wave per row; the row is read twice (the second read hits L2).
+template <typename OutT>
+__global__ __launch_bounds__(256) void append_normalized_kernel(const float *__restrict__ src, long long ld_src,
+                                                                long long b, int D, OutT *__restrict__ bank,
+                                                                long long ld, long long row0, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= b) return;
+    const float *x = src + r * ld_src;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) ss = fmaf(x[c], x[c], ss);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d, 64);
+    const float denom = fmaxf(sqrtf(ss), eps);                      // F.normalize: v / max(||v||_2, eps)
+    OutT *o = bank + (row0 + r) * ld;
+    for (int c = lane; c < (int)ld; c += 64) o[c] = (OutT)(c < D ? x[c] / denom : 0.f);
+}
+
 __global__ void init_state_kernel(float *tau, unsigned *cnt, int *topk_n, unsigned *big_cnt, int B, int B_pad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,6 +433,23 @@ int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows,
         if (transposed) hipLaunchKernelGGL((pack_kernel<float, true>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (float *)dst, ld_dst);
         else hipLaunchKernelGGL((pack_kernel<float, false>), grid, dim3(256), 0, s, src, ld_src, rows, (int)D, (float *)dst, ld_dst);
     }
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_bank_append_normalized(const float *src, int64_t ld_src, int64_t b, int64_t D, int dtype,
+                              void *bank, int64_t ld, int64_t n_rows, int64_t row0, float eps, mi_stream_t stream)
+{
+    if (!src || !bank) return fail(MI_ERR_ARG, "mi_bank_append_normalized: null pointer");
+    if (dtype != MI_F32 && dtype != MI_BF16) return fail(MI_ERR_ARG, "mi_bank_append_normalized: bad dtype %d", dtype);
+    if (b < 0 || D < 1 || ld_src < D || D > INT32_MAX / 2) return fail(MI_ERR_ARG, "mi_bank_append_normalized: bad shape b=%lld D=%lld ld_src=%lld", (long long)b, (long long)D, (long long)ld_src);
+    if (ld != mi_knn_ld(D, dtype)) return fail(MI_ERR_ARG, "mi_bank_append_normalized: ld must equal mi_knn_ld(D)=%lld (got %lld)", (long long)mi_knn_ld(D, dtype), (long long)ld);
+    if (row0 < 0 || row0 + b > n_rows) return fail(MI_ERR_ARG, "mi_bank_append_normalized: rows [%lld, %lld) do not fit a bank of %lld rows", (long long)row0, (long long)(row0 + b), (long long)n_rows);
+    if (!(eps >= 0.f)) return fail(MI_ERR_ARG, "mi_bank_append_normalized: eps must be non-negative");
+    if (b == 0) return MI_OK;
+    const dim3 grid((unsigned)ceil_div(b, 4));
+    if (dtype == MI_BF16) hipLaunchKernelGGL((append_normalized_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (__bf16 *)bank, ld, row0, eps);
+    else hipLaunchKernelGGL((append_normalized_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (float *)bank, ld, row0, eps);
     HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

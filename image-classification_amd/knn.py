@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex",
+__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
            "pack_rows", "DEFAULT_COMPUTE_DTYPE"]
 
 # "fp32": exact float32 products, one k-ascending fma chain per similarity (the parity mode);
@@ -129,6 +129,49 @@ class BankIndex:
     @property
     def device(self):
         return self.packed.data.device
+
+
+class BankBuilder:
+    """Builds a :class:`BankIndex` batch by batch, the way ``knn_test`` walks the memo loader
+    (``ssltrainer.py:172-179``) -- without the reference's ``F.normalize`` pass, ``torch.cat`` and
+    ``.t().contiguous()`` transpose:
+
+        builder = BankBuilder(n_rows, feature_dim, device, compute_dtype="bf16")
+        for batch in memo_loader:
+            builder.append(to_feature(batch["xs"]))        # L2-normalised and packed in one kernel
+        pred = knn_predict(test_feature, builder.finish(), feature_labels, classes, 200, 0.1)
+
+    ``idx_base`` makes the result one row shard of a larger bank."""
+
+    def __init__(self, n_rows: int, dim: int, device, compute_dtype=None, idx_base: int = 0, eps: float = 1e-12):
+        self.code = _dtype_code(compute_dtype)
+        self.n_rows, self.dim, self.idx_base, self.eps = int(n_rows), int(dim), int(idx_base), float(eps)
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"BankBuilder needs an MI355X (HIP) device, got {device}: there is no CPU fallback")
+        self.ld = int(_lib.lib().mi_knn_ld(self.dim, self.code))
+        self.data = torch.empty((self.n_rows, self.ld), dtype=_TORCH_DT[self.code], device=device)
+        self.filled = 0
+
+    def append(self, feature: torch.Tensor) -> None:
+        _require_device(feature, "feature")
+        if feature.dim() != 2 or feature.shape[1] != self.dim:
+            raise ValueError(f"feature must be [b, {self.dim}], got {tuple(feature.shape)}")
+        src = feature.detach()
+        if src.dtype != torch.float32:
+            src = src.float()
+        if src.stride(1) != 1:
+            src = src.contiguous()
+        with torch.cuda.device(self.data.device):
+            _lib.check(_lib.lib().mi_bank_append_normalized(src.data_ptr(), src.stride(0), src.shape[0], self.dim, self.code,
+                                                            self.data.data_ptr(), self.ld, self.n_rows, self.filled, self.eps,
+                                                            _lib.stream_ptr(self.data.device)), "mi_bank_append_normalized")
+        self.filled += src.shape[0]
+
+    def finish(self) -> "BankIndex":
+        if self.filled != self.n_rows:
+            raise RuntimeError(f"bank holds {self.filled} of {self.n_rows} rows")
+        return BankIndex(PackedRows(self.data, self.n_rows, self.dim, self.code), self.idx_base)
 
 
 def knn_topk(feature: torch.Tensor, bank: BankIndex, k: int) -> Tuple[torch.Tensor, torch.Tensor]:

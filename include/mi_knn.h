@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -57,6 +57,15 @@ int64_t mi_knn_ld(int64_t D, int dtype);
  * Replaces: the layout/dtype handling torch.mm does implicitly at models/knn.py:6. */
 int mi_pack_rows(const float *src, int64_t ld_src, int transposed, int64_t rows, int64_t D,
                  int dtype, void *dst, int64_t ld_dst, mi_stream_t stream);
+
+/* Bank construction without the reference's three extra passes.  Replaces track_ssl/ssltrainer.py:176-179
+ * (per memo batch `F.normalize(feature, dim=1)`, then `cat(...).t().contiguous()`): the b rows of one batch
+ * are L2-normalised (v / max(||v||_2, eps), eps = 1e-12 in F.normalize) and written, in the compute dtype
+ * and zero padded, to rows [row0, row0 + b) of a pre-allocated packed bank [n_rows, ld]
+ * (ld == mi_knn_ld(D, dtype)) -- directly the layout mi_knn_topk reads, and directly into a rank's row shard.
+ * src is [b, D] float32 with leading dimension ld_src. */
+int mi_bank_append_normalized(const float *src, int64_t ld_src, int64_t b, int64_t D, int dtype,
+                              void *bank, int64_t ld, int64_t n_rows, int64_t row0, float eps, mi_stream_t stream);
 
 /* Recommended workspace (bytes) for mi_knn_topk: fixed per-row state plus a candidate buffer of
  * up to 8 GiB.  mi_knn_topk sizes its filter stages by the workspace it is actually given: the

@@ -118,3 +118,52 @@ def test_monitor_flow_like_ssltrainer(ica):
     acc = torch.eq(pred[:, 0], sb["test_ys"]).float().sum().item() / B * 100
     acc_ref = ko.knn_monitor_accuracy(f, ys, x.astype(np.float32), lab, C, 200, 0.1)
     assert abs(acc - acc_ref) <= 100.0 / B + 1e-9, (acc, acc_ref)
+
+
+@pytest.mark.parametrize("dtype,D", [("fp32", 128), ("bf16", 128), ("fp32", 50), ("bf16", 2048)])
+def test_bank_builder_normalises_and_packs(ica, dtype, D):
+    """Next row 8(f)1: ssltrainer.py:172-179 (F.normalize per memo batch, cat, t().contiguous()) in one kernel per
+    batch.  Floating point: each stored element within 2 float32 ulp of the float64 oracle normalisation (the
+    norm's summation order differs from torch's); bf16 storage = that value rounded to nearest-even, so at most
+    one bf16 ulp apart and equal almost everywhere."""
+    rs = np.random.RandomState(D)
+    N = 1000
+    x = (rs.randn(N, D) * rs.uniform(0.1, 30.0, size=(N, 1))).astype(np.float32)
+    x[17] = 0.0                                             # zero row: 0 / max(0, eps) = 0, as F.normalize
+    b = ica.BankBuilder(N, D, "cuda", compute_dtype=dtype)
+    for s in range(0, N, 192):                              # ragged last batch
+        b.append(torch.from_numpy(x[s:s + 192]).cuda())
+    bank = b.finish()
+    got = bank.packed.data.float().cpu().numpy()
+    ref = ko.l2_normalize(x)
+    assert got.shape[1] == int(ica._lib.lib().mi_knn_ld(D, 0 if dtype == "fp32" else 1))
+    assert np.all(got[:, D:] == 0) and np.all(got[17] == 0)
+    if dtype == "fp32":
+        assert np.max(np.abs(got[:, :D] - ref) / np.maximum(np.abs(ref), 1e-30)) <= 3e-7
+    else:
+        refb = ko.bf16_round(ref)
+        assert np.max(np.abs(got[:, :D] - refb)) <= np.max(np.abs(refb)) * 2.0 ** -7
+        assert np.mean(got[:, :D] == refb) > 0.995
+    with pytest.raises(ValueError):
+        b.append(torch.zeros(1, D).cuda())                  # bank is full
+    with pytest.raises(ValueError):
+        ica.BankBuilder(10, D, "cuda", compute_dtype=dtype).append(torch.zeros(3, D + 1).cuda())
+
+
+def test_bank_builder_flow_equals_reference_flow(ica):
+    """knn_test with the builder == knn_test with F.normalize + cat + t().contiguous() + knn_predict (top-1 labels)."""
+    rs = np.random.RandomState(9)
+    C, D, N, B = 10, 128, 4000, 600
+    cent = rs.randn(C, D)
+    lab = rs.randint(0, C, size=N)
+    x = (cent[lab] + 0.7 * rs.randn(N, D)).astype(np.float32)
+    f = torch.from_numpy(ko.l2_normalize(cent[rs.randint(0, C, size=B)] + 0.7 * rs.randn(B, D))).cuda()
+    tl = torch.from_numpy(lab).cuda()
+    xb = torch.from_numpy(x).cuda()
+    ref_bank = torch.cat([torch.nn.functional.normalize(xb[s:s + 512], dim=1) for s in range(0, N, 512)], 0).t().contiguous()
+    ref = ica.knn_predict(f, ref_bank, tl, C, 200, 0.1)
+    b = ica.BankBuilder(N, D, "cuda", compute_dtype="fp32")
+    for s in range(0, N, 512):
+        b.append(xb[s:s + 512])
+    got = ica.knn_predict(f, b.finish(), tl, C, 200, 0.1)
+    assert (got[:, 0] == ref[:, 0]).float().mean().item() >= 0.995       # 1-ulp bank differences can flip a near-tie
