@@ -4,10 +4,11 @@ One hot path of sailist/image-classification, rebuilt for gfx950: the weighted-k
 (``models/knn.py``) and the MoCo queue (``models/memory_bank.py``, ``track_ssl/moco.py``).
 Import as ``image_classification_amd`` (alias module at the repository root)."""
 from . import _lib
+from . import module_utils
 from . import sharded
 from .knn import BankBuilder, BankIndex, knn_merge, knn_predict, knn_predict_full, knn_topk, knn_vote, pack_rows
 from .memory_bank import MemoryBank, StorageBank
 from .moco import contrastive_loss2, moco_queue_loss
 
 __all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
-           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "sharded", "_lib"]
+           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "sharded", "module_utils", "_lib"]

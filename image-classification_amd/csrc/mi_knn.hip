@@ -187,6 +187,22 @@ __global__ void push_kernel(char *__restrict__ dst, const char *__restrict__ src
     }
 }
 
+// wrapping ring-buffer enqueue (models/module_utils.py:73-85): item row r -> queue row (cursor + r) % K
+__global__ void push_wrap_kernel(char *__restrict__ queue, long long K, long long row_bytes, long long cursor,
+                                 const char *__restrict__ value, long long b, int vec)
+{
+    const long long per = vec ? row_bytes >> 4 : row_bytes;
+    const long long total = b * per;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i / per, c = i - r * per;
+        long long dst = cursor + r;
+        if (dst >= K) dst -= K;
+        if (vec) ((uint4 *)(queue + dst * row_bytes))[c] = ((const uint4 *)(value + r * row_bytes))[c];
+        else queue[dst * row_bytes + c] = value[r * row_bytes + c];
+    }
+}
+
 // StorageBank.scatter body: bank[index[i]] = value[i] (rows of row_bytes); out-of-range indices are skipped
 __global__ void scatter_rows_kernel(char *__restrict__ bank, long long K, long long row_bytes,
                                     const long long *__restrict__ index, const char *__restrict__ value,
@@ -626,6 +642,25 @@ int mi_queue_push(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
         HIP_CHECK(hipGetLastError());
     }
     if (new_ptr) *new_ptr = (ptr + w) % K;
+    return MI_OK;
+}
+
+int mi_queue_push_wrap(void *queue, int64_t K, int64_t row_bytes, int64_t cursor,
+                       const void *value, int64_t b, int64_t *new_cursor, mi_stream_t stream)
+{
+    if (!queue || !value) return fail(MI_ERR_ARG, "mi_queue_push_wrap: null pointer");
+    if (K < 1 || row_bytes < 1 || b < 0 || cursor < 0 || cursor >= K) return fail(MI_ERR_ARG, "mi_queue_push_wrap: bad shape K=%lld row_bytes=%lld b=%lld cursor=%lld", (long long)K, (long long)row_bytes, (long long)b, (long long)cursor);
+    if (b > K) return fail(MI_ERR_ARG, "mi_queue_push_wrap: shape mismatch: %lld rows do not fit a queue of %lld (the reference's second slice assignment fails the same way)", (long long)b, (long long)K);
+    if (b > 0) {
+        const int vec = ((((uintptr_t)queue | (uintptr_t)value) & 15) == 0 && (row_bytes & 15) == 0) ? 1 : 0;
+        const long long items = b * (vec ? row_bytes >> 4 : row_bytes);
+        int grid = (int)ceil_div(items, 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(push_wrap_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (char *)queue, (long long)K,
+                           (long long)row_bytes, (long long)cursor, (const char *)value, (long long)b, vec);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (new_cursor) *new_cursor = (cursor + b) % K;
     return MI_OK;
 }
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -115,6 +115,14 @@ int mi_knn_vote(const float *val, const int64_t *idx, const int64_t *labels, int
  * the reference does.  row_bytes = bytes of one queue row (any dtype). */
 int mi_queue_push(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
                   const void *value, int64_t b, int64_t *new_ptr, mi_stream_t stream);
+
+/* WRAPPING ring-buffer enqueue.  Replaces models/module_utils.py:73-85 (MemoryBank.push and
+ * LongTensorMemoryBank.push:125-136, the queues of supcontrast/ft/infomin/cmc/swav/byol): value row r goes
+ * to queue row (cursor + r) % K -- the overflow wraps to the front instead of being dropped -- and the new
+ * cursor (cursor + b) % K is stored to *new_cursor (HOST pointer, may be NULL).  b > K is an error, as in the
+ * reference (its second slice assignment cannot fit). */
+int mi_queue_push_wrap(void *queue, int64_t K, int64_t row_bytes, int64_t cursor,
+                       const void *value, int64_t b, int64_t *new_cursor, mi_stream_t stream);
 
 /* Index-addressed row store.  Replaces models/memory_bank.py:32 (StorageBank.scatter:
  * `self[name][index] = value`): bank[index[i]] = value[i] for i < b; rows of row_bytes bytes.

@@ -21,6 +21,7 @@ Reference lines followed (all under /root/reference):
   * ``models/knn.py:20``     argsort(descending)                     -> :func:`rank_classes`
   * ``models/memory_bank.py:14-32``  StorageBank                     -> :class:`StorageBankOracle`
   * ``models/memory_bank.py:43-72``  MemoryBank (truncating ring)    -> :class:`MemoryBankOracle`
+  * ``models/module_utils.py:48-148`` wrapping MemoryBank / LongTensorMemoryBank -> :class:`WrappingQueueOracle`
   * ``track_ssl/ssltrainer.py:166-190`` harness (normalise, transpose, column-0 accuracy)
                                                                      -> :func:`knn_monitor_accuracy`
   * ``track_ssl/moco.py:103-106,152-163`` queue init / logits / push-before-backward
@@ -209,6 +210,32 @@ class MemoryBankOracle:
             value = value[:b]
         buf[ptr:ptr + b] = value
         self.offsets[name] = (ptr + b) % K
+
+
+class WrappingQueueOracle:
+    """models/module_utils.py:48-98 (MemoryBank) / :100-148 (LongTensorMemoryBank): the WRAPPING ring.
+    ``push`` writes ``item[:right]`` at the cursor and ``item[right:]`` at the front (``:78-85``); a batch
+    longer than the queue raises, as the reference's second slice assignment does."""
+
+    def __init__(self, queue_size=65535, feature_dim=128, dtype=F32, rng=None):
+        rng = rng or np.random.RandomState(0)
+        shape = (queue_size,) if feature_dim is None else (queue_size, feature_dim)
+        self.data = rng.rand(*shape).astype(dtype) if np.dtype(dtype).kind == "f" else np.zeros(shape, dtype)
+        self.queue_size, self.cursor = queue_size, 0
+
+    def push(self, item):
+        item = np.asarray(item)
+        isize = len(item)
+        if self.cursor + isize > self.queue_size:
+            right = self.queue_size - self.cursor
+            left = isize - right
+            if left > self.queue_size:
+                raise RuntimeError("shape mismatch: batch longer than the queue")
+            self.data[self.cursor:] = item[:right]
+            self.data[:left] = item[right:]
+        else:
+            self.data[self.cursor:self.cursor + isize] = item
+        self.cursor = (self.cursor + isize) % self.queue_size
 
 
 def ring_push_plan(ptr: int, K: int, b: int):

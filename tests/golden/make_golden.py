@@ -202,6 +202,55 @@ def bank_cases():
           final_ys=sb["test_ys"].numpy(), sizes=np.array([sb.sizes["test_feature"], sb.sizes["test_ys"]]))
 
 
+def wrapping_queue_cases():
+    """models/module_utils.py MemoryBank / LongTensorMemoryBank (the WRAPPING ring).
+    The module imports ``lumo.core.BaseParams`` for an unrelated class (ModelParams); the absent
+    third-party package is again satisfied with an inert placeholder, the two queue classes run as written."""
+    for modname in ("lumo", "lumo.core"):
+        sys.modules.setdefault(modname, types.ModuleType(modname))
+    sys.modules["lumo.core"].BaseParams = type("BaseParams", (), {})
+    from models.module_utils import LongTensorMemoryBank, MemoryBank  # the reference
+
+    out = {}
+    for tag, (K, b, dim, n_push) in {
+        "k10_b4": (10, 4, 3, 7),                 # wraps with a two-segment write
+        "k4096_b512": (4096, 512, 2, 11),
+        "k65535_b512": (65535, 512, 1, 130),
+        "k7_b7": (7, 7, 2, 3),                   # batch == queue
+        "k9_b5": (9, 5, 1, 9),
+    }.items():
+        torch.manual_seed(0)
+        mb = MemoryBank(queue_size=K, feature_dim=dim)
+        cursors = [mb.cursor]
+        for p in range(n_push):
+            val = (torch.arange(b, dtype=torch.float32) + 1000.0 * (p + 1))[:, None].expand(b, dim).contiguous()
+            mb.push(val)
+            cursors.append(mb.cursor)
+        out[f"{tag}_params"] = np.array([K, b, dim, n_push], np.int64)
+        out[f"{tag}_cursors"] = np.array(cursors, np.int64)
+        final = mb.tensor().numpy()
+        out[f"{tag}_final"] = np.where(final[:, 0] >= 1000.0, final[:, 0], -1.0).astype(np.float32)   # rand init < 1
+    lb = LongTensorMemoryBank(queue_size=11)
+    cur = [lb.cursor]
+    for p in range(6):
+        lb.push(torch.arange(4, dtype=torch.long) + 100 * (p + 1))
+        cur.append(lb.cursor)
+    out["long_k11_b4_cursors"] = np.array(cur, np.int64)
+    out["long_k11_b4_final"] = lb.tensor().numpy()
+    # batch larger than the queue: the reference's second slice assignment cannot fit -> RuntimeError
+    try:
+        MemoryBank(queue_size=5, feature_dim=2).push(torch.zeros(12, 2))
+        too_big = "ok"
+    except RuntimeError:
+        too_big = "RuntimeError"
+    out["oversized_push"] = np.array([too_big])
+    c = MemoryBank(queue_size=6, feature_dim=2)
+    c.push(torch.ones(4, 2))
+    out["attrs_survive"] = np.array([c.clone().cursor, c.to(torch.float64).cursor, c.clone().queue_size], np.int64)
+    _save("wrapping_queue", **out)
+
+
 if __name__ == "__main__":
     knn_cases()
     bank_cases()
+    wrapping_queue_cases()
