@@ -9,6 +9,7 @@ from . import sharded
 from .knn import BankBuilder, BankIndex, knn_merge, knn_predict, knn_predict_full, knn_topk, knn_vote, pack_rows
 from .memory_bank import MemoryBank, StorageBank
 from .moco import contrastive_loss2, moco_queue_loss
+from .soft_knn import smooth_prob
 
 __all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
-           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "sharded", "module_utils", "_lib"]
+           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "smooth_prob", "sharded", "module_utils", "_lib"]

@@ -764,9 +764,9 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
     const MocoPlan mp = moco_plan(b, K, D);
     if (workspace_bytes < mp.bwd_total) return fail(MI_ERR_WORKSPACE, "mi_moco_bwd: workspace %zu < required %zu", workspace_bytes, mp.bwd_total);
     hipStream_t s = (hipStream_t)stream;
-    mi::MocoBwdParams bp{};
+    mi::AttendParams bp{};
     bp.q = q;
-    bp.queue = queue;
+    bp.bank = queue;
     bp.lse = lse;
     bp.patch = patch_n > 0 ? patch_rows : nullptr;
     bp.patch_lo = (int)patch_lo;
@@ -777,13 +777,13 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
     bp.part = (float *)workspace;
     bp.rows_per_slice = mp.rows_per_slice;
     const dim3 grid((unsigned)ceil_div(b, mi::MB_ROWS), (unsigned)mp.nslices);
-    const size_t lds = mi::moco_bwd_lds_bytes((int)D);
+    const size_t lds = mi::attend_lds_bytes((int)D, (int)D, false);
     {
         ProfScope ps(MI_PROF_MOCO_BWD, 4.0 * (double)b * (double)K * (double)D, s);
 #define MI_LAUNCH_BWD(D64)                                                                                       \
         do {                                                                                                    \
-            HIP_CHECK(hipFuncSetAttribute((const void *)mi::moco_bwd_kernel<D64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((mi::moco_bwd_kernel<D64>), grid, dim3(mi::MB_THREADS), lds, s, bp);             \
+            HIP_CHECK(hipFuncSetAttribute((const void *)mi::attend_kernel<D64, D64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((mi::attend_kernel<D64, D64, false>), grid, dim3(mi::MB_THREADS), lds, s, bp);   \
         } while (0)
         switch ((int)(D / 64)) {
         case 1: MI_LAUNCH_BWD(1); break;
@@ -797,6 +797,92 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
                            (const float *)workspace, mp.nslices, (int)b, (int)D, key, lse, lpos, grad_loss, bp.inv_t, dq);
         HIP_CHECK(hipGetLastError());
     }
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ CoMatch soft-kNN smoothing
+extern "C++" {
+namespace {
+struct SoftPlan { int V, nslices, rows_per_slice; size_t total; };
+SoftPlan soft_plan(int64_t b, int64_t K, int64_t C)
+{
+    SoftPlan sp{};
+    sp.V = (int)round_up(C + 1, 64);                       // + the row-sum column
+    const int64_t qtiles = ceil_div(b, mi::MB_ROWS), ktiles = ceil_div(K, mi::MB_ROWS);
+    int64_t ns = ceil_div(256, qtiles);
+    if (ns > ktiles) ns = ktiles;
+    if (ns < 1) ns = 1;
+    sp.rows_per_slice = (int)(ceil_div(ktiles, ns) * mi::MB_ROWS);
+    sp.nslices = (int)ceil_div(K, sp.rows_per_slice);
+    sp.total = (size_t)round_up((int64_t)sp.nslices * b * sp.V * 4, 256);
+    return sp;
+}
+
+template <int D64, int V64>
+hipError_t launch_soft(const mi::AttendParams &ap, dim3 grid, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)mi::attend_kernel<D64, V64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mi::attend_kernel<D64, V64, true>), grid, dim3(mi::MB_THREADS), lds, s, ap);
+    return hipGetLastError();
+}
+template <int D64>
+hipError_t launch_soft_v(int v64, const mi::AttendParams &ap, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (v64) {
+    case 1: return launch_soft<D64, 1>(ap, grid, lds, s);
+    case 2: return launch_soft<D64, 2>(ap, grid, lds, s);
+    case 3: return launch_soft<D64, 3>(ap, grid, lds, s);
+    default: return launch_soft<D64, 4>(ap, grid, lds, s);
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+size_t mi_soft_knn_workspace_bytes(int64_t b, int64_t K, int64_t D, int64_t C)
+{
+    if (b <= 0 || K <= 0 || D <= 0 || C <= 0 || C > 255) return 0;
+    return soft_plan(b, K, C).total;
+}
+
+int mi_soft_knn(const float *feature, const float *bank_feature, const float *bank_prob, const float *probs_in,
+                int64_t b, int64_t K, int64_t D, int64_t C, float temperature, float alpha, float *probs_out,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream)
+{
+    if (!feature || !bank_feature || !bank_prob || !probs_in || !probs_out || !workspace) return fail(MI_ERR_ARG, "mi_soft_knn: null pointer");
+    if (b < 1 || K < 1 || b > (1 << 24) || K > INT32_MAX - 2 * mi::TILE) return fail(MI_ERR_ARG, "mi_soft_knn: bad shape b=%lld K=%lld", (long long)b, (long long)K);
+    if (D % 64 || D < 64 || D > 256) return fail(MI_ERR_UNSUPPORTED, "mi_soft_knn: D=%lld must be a multiple of 64 in [64, 256]", (long long)D);
+    if (C < 1 || C > 255) return fail(MI_ERR_UNSUPPORTED, "mi_soft_knn: C=%lld outside [1, 255]", (long long)C);
+    if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_soft_knn: temperature must be positive");
+    if (((uintptr_t)feature | (uintptr_t)bank_feature | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_soft_knn: feature, bank_feature, workspace must be 16-byte aligned");
+    const SoftPlan sp = soft_plan(b, K, C);
+    if (workspace_bytes < sp.total) return fail(MI_ERR_WORKSPACE, "mi_soft_knn: workspace %zu < required %zu", workspace_bytes, sp.total);
+    const size_t lds = mi::attend_lds_bytes((int)D, sp.V, true);
+    if (lds > 160 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_soft_knn: D=%lld with C=%lld needs %zu bytes of LDS (> 160 KiB)", (long long)D, (long long)C, lds);
+    hipStream_t s = (hipStream_t)stream;
+    mi::AttendParams ap{};
+    ap.q = feature;
+    ap.bank = bank_feature;
+    ap.vals = bank_prob;
+    ap.C = (int)C;
+    ap.b = (int)b;
+    ap.K = (int)K;
+    ap.inv_t = 1.0f / temperature;
+    ap.part = (float *)workspace;
+    ap.rows_per_slice = sp.rows_per_slice;
+    const dim3 grid((unsigned)ceil_div(b, mi::MB_ROWS), (unsigned)sp.nslices);
+    const int v64 = sp.V / 64;
+    hipError_t e;
+    switch ((int)(D / 64)) {
+    case 1: e = launch_soft_v<1>(v64, ap, grid, lds, s); break;
+    case 2: e = launch_soft_v<2>(v64, ap, grid, lds, s); break;
+    case 3: e = launch_soft_v<3>(v64, ap, grid, lds, s); break;
+    default: e = launch_soft_v<4>(v64, ap, grid, lds, s); break;
+    }
+    HIP_CHECK(e);
+    hipLaunchKernelGGL(mi::soft_knn_reduce_kernel, dim3((unsigned)ceil_div(b * C, 256)), dim3(256), 0, s,
+                       (const float *)workspace, sp.nslices, (int)b, sp.V, (int)C, probs_in, alpha, probs_out);
+    HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
 

@@ -1,17 +1,21 @@
-// moco_kernel.h -- backward of the MoCo queue InfoNCE w.r.t. the query (track_ssl/moco.py:152-156,172).
+// moco_kernel.h -- "attend over a feature bank" kernels: exp-weighted sums of bank rows per query that never
+// write the [b, K] weight matrix.  Two users:
 //
-//   p[i][n] = exp(q_i . queue_n / T - lse_i)                       (softmax over [pos, queue])
-//   dq_i    = g / (b T) * ( sum_n p[i][n] queue_n + (p_pos[i] - 1) key_i )
+//  * MoCo queue InfoNCE, backward w.r.t. the query (track_ssl/moco.py:152-156,172):
+//        p[i][n] = exp(q_i . queue_n / T - lse_i)                     (softmax over [pos, queue])
+//        dq_i    = g / (b T) * ( sum_n p[i][n] queue_n + (p_pos[i] - 1) key_i )
+//    The queue may have been overwritten between forward and backward (MemoryBank.push precedes backward at
+//    moco.py:159-172).  Instead of the reference's full clone() per step the caller stashes only the
+//    overwritten rows: rows [patch_lo, patch_lo + patch_n) are read from `patch`.
 //
-// The [b, K] logits / probabilities are never written: a workgroup owns 64 query rows and one
-// slice of the queue, recomputes S = q . queue_tile^T for 64 queue rows at a time with fp32 MFMA,
-// turns it into P in registers, transposes P through a wave-private LDS patch and accumulates
-// P . queue_tile into its [64, D] partial of dq (fp32 MFMA again).  Slices are summed by a second
+//  * CoMatch soft-kNN pseudo-label smoothing (track_semi/comatch.py:187-189):
+//        A[i][n] = exp(f_i . bank_n / T) ;  probs_i = alpha p_i + (1 - alpha) sum_n A[i][n] prob_n / sum_n A[i][n]
+//    (plain exp, no max subtraction -- as the reference; the row sum rides as one extra value column of ones).
+//
+// A workgroup owns 64 query rows and one slice of the bank, recomputes S = q . tile^T for 64 bank rows at a
+// time with fp32 MFMA, turns it into weights in registers, transposes them through a wave-private LDS patch
+// and accumulates weights . values into its [64, V] partial (fp32 MFMA again).  Slices are summed by a second
 // kernel in slice order, so the result does not depend on scheduling.
-//
-// The queue may have been overwritten between forward and backward (MemoryBank.push precedes
-// backward at moco.py:159-172).  Instead of the reference's full clone() per step the caller
-// stashes only the overwritten rows: rows [patch_lo, patch_lo + patch_n) are read from `patch`.
 //
 // MFMA operand maps (v_mfma_f32_16x16x4_f32): A lane -> (row = lane & 15, k = lane >> 4),
 // B lane -> (col = lane & 15, k = lane >> 4), C/D lane -> (col = lane & 15, row = 4 * (lane >> 4) + reg).
@@ -23,34 +27,43 @@
 
 namespace mi {
 
-constexpr int MB_ROWS = 64;        // query rows and queue rows per tile
+constexpr int MB_ROWS = 64;        // query rows and bank rows per tile
 constexpr int MB_THREADS = 256;    // 4 waves, wave w owns query rows 16w .. 16w+15
-constexpr int MB_PLD = 68;         // leading dimension of the wave-private P patch
+constexpr int MB_PLD = 68;         // leading dimension of the wave-private weight patch
 
-struct MocoBwdParams {
+struct AttendParams {
     const float *q;            // [b, D]
-    const float *queue;        // [K, D]
-    const float *lse;          // [b]
-    const float *patch;        // [patch_n, D] pre-push contents of queue rows [patch_lo, patch_lo + patch_n), or nullptr
+    const float *bank;         // [K, D]
+    const float *lse;          // [b] (MoCo) or nullptr (soft-kNN: weights are exp(S / T))
+    const float *patch;        // [patch_n, D] pre-push contents of bank rows [patch_lo, patch_lo + patch_n), or nullptr
     int patch_lo, patch_n;
+    const float *vals;         // soft-kNN: [K, C] values; column C of the LDS image is 1 (row sum)
+    int C;
     int b, K;
     float inv_t;
-    float *part;               // [nslices, b, D]
+    float *part;               // [nslices, b, V]   V = D (MoCo) or V64 * 64 (soft-kNN)
     int rows_per_slice;        // multiple of MB_ROWS
 };
 
-inline size_t moco_bwd_lds_bytes(int D) { return (size_t)(2 * MB_ROWS * (D + 4) + 4 * 16 * MB_PLD) * 4; }
+inline size_t attend_lds_bytes(int D, int V, bool separate_vals)
+{
+    return (size_t)(2 * MB_ROWS * (D + 4) + (separate_vals ? MB_ROWS * (V + 4) : 0) + 4 * 16 * MB_PLD) * 4;
+}
 
-template <int D64>             // D / 64
-__global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParams p)
+template <int D64, int V64, bool SOFT>      // D / 64, V / 64 (values); !SOFT: the values ARE the bank rows (V64 == D64)
+__global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p)
 {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     constexpr int D = D64 * 64, LD = D + 4;
-    constexpr int LOADS = MB_ROWS * D / 4 / MB_THREADS;      // float4 per thread and tile = D / 16
+    constexpr int V = V64 * 64, LV = V + 4;
+    constexpr int LOADS = MB_ROWS * D / 4 / MB_THREADS;      // float4 per thread and feature tile = D / 16
+    constexpr int VLOADS = SOFT ? MB_ROWS * V / MB_THREADS : 1;   // floats per thread and value tile = V / 4
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *sq = lds;                       // [64][LD] query tile
-    float *sx = sq + MB_ROWS * LD;         // [64][LD] queue tile
-    float *sp = sx + MB_ROWS * LD;         // [4][16][MB_PLD] P, one patch per wave
+    float *sq = lds;                                  // [64][LD] query tile
+    float *sx = sq + MB_ROWS * LD;                    // [64][LD] bank tile
+    float *sv = SOFT ? sx + MB_ROWS * LD : sx;        // [64][LV] value tile (soft-kNN) / the bank tile itself
+    float *sp = sv + (SOFT ? MB_ROWS * LV : MB_ROWS * LD);   // [4][16][MB_PLD] weights, one patch per wave
+    constexpr int SLD = SOFT ? LV : LD;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -60,15 +73,27 @@ __global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParam
 
     auto tile_row_ptr = [&](int n) -> const float * {
         if (n >= p.patch_lo && n < p.patch_lo + p.patch_n) return p.patch + (long long)(n - p.patch_lo) * D;
-        return p.queue + (long long)n * D;
+        return p.bank + (long long)n * D;
     };
     float4 pre[LOADS];
+    float vpre[VLOADS];
     auto prefetch = [&](int n0) {
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
             const int n = n0 + r;
             pre[i] = n < n_end ? *(const float4 *)(tile_row_ptr(n) + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr (SOFT) {
+            // value tile: element e -> (row e / V, column e % V); C is arbitrary, so scalar loads; column C = 1
+#pragma unroll
+            for (int i = 0; i < VLOADS; ++i) {
+                const int e = tid + i * MB_THREADS, r = e / V, c = e % V;
+                const int n = n0 + r;
+                float v = 0.f;
+                if (n < n_end) v = c < p.C ? p.vals[(long long)n * p.C + c] : (c == p.C ? 1.f : 0.f);
+                vpre[i] = v;
+            }
         }
     };
     auto commit = [&]() {
@@ -77,9 +102,17 @@ __global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParam
             const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
             *(float4 *)(sx + r * LD + c * 4) = pre[i];
         }
+        if constexpr (SOFT) {
+#pragma unroll
+            for (int i = 0; i < VLOADS; ++i) {
+                const int e = tid + i * MB_THREADS, r = e / V, c = e % V;
+                sv[r * LV + c] = vpre[i];
+            }
+        }
     };
 
-    // query tile -> LDS (rows past b are zero and get lse = +inf below: their P is exactly 0)
+    // query tile -> LDS (rows past b are zero; MoCo gives them lse = +inf below: their weight is exactly 0;
+    // soft-kNN rows past b are simply not written out)
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
         const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
@@ -91,11 +124,11 @@ __global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParam
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = q0 + 16 * w + 4 * lq + r;
-        lse_r[r] = row < p.b ? p.lse[row] : INFINITY;
+        lse_r[r] = SOFT ? 0.f : (row < p.b ? p.lse[row] : INFINITY);
     }
-    f32x4 acc[D64 * 4];
+    f32x4 acc[V64 * 4];
 #pragma unroll
-    for (int i = 0; i < D64 * 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < V64 * 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float *spw = sp + w * 16 * MB_PLD;
     if (n_begin < n_end) prefetch(n_begin);
@@ -121,22 +154,26 @@ __global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParam
                 s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, s[nb], 0, 0, 0);
             }
         }
-        // P = exp(S / T - lse), columns past the slice end are 0; C layout -> LDS patch [row][n]
+        // weights = exp(S / T - lse), columns past the slice end are 0; C layout -> LDS patch [row][n]
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const bool ok = (n0 + 16 * nb + lr) < n_end;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                spw[(4 * lq + r) * MB_PLD + 16 * nb + lr] = ok ? __expf(s[nb][r] * p.inv_t - lse_r[r]) : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                float wgt;
+                if constexpr (SOFT) wgt = expf(s[nb][r] * p.inv_t);
+                else wgt = __expf(s[nb][r] * p.inv_t - lse_r[r]);
+                spw[(4 * lq + r) * MB_PLD + 16 * nb + lr] = ok ? wgt : 0.f;
+            }
         }
         __syncthreads();
-        // dq[16 x D] += P[16 x 64] . tile[64 x D]; block c*4+j holds columns 64c + 4*(lane&15) + j
+        // out[16 x V] += W[16 x 64] . values[64 x V]; block c*4+j holds columns 64c + 4*(lane&15) + j
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const float a = spw[lr * MB_PLD + 4 * kk + lq];
 #pragma unroll
-            for (int c = 0; c < D64; ++c) {
-                const float4 x = *(const float4 *)(sx + (4 * kk + lq) * LD + 64 * c + 4 * lr);
+            for (int c = 0; c < V64; ++c) {
+                const float4 x = *(const float4 *)(sv + (4 * kk + lq) * SLD + 64 * c + 4 * lr);
                 acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.x, acc[c * 4 + 0], 0, 0, 0);
                 acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.y, acc[c * 4 + 1], 0, 0, 0);
                 acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.z, acc[c * 4 + 2], 0, 0, 0);
@@ -145,14 +182,14 @@ __global__ __launch_bounds__(MB_THREADS) void moco_bwd_kernel(const MocoBwdParam
         }
     }
     // partial of this slice
-    float *part = p.part + (long long)blockIdx.y * p.b * D;
+    float *part = p.part + (long long)blockIdx.y * p.b * V;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = q0 + 16 * w + 4 * lq + r;
         if (row < p.b) {
 #pragma unroll
-            for (int c = 0; c < D64; ++c)
-                *(float4 *)(part + (long long)row * D + 64 * c + 4 * lr) =
+            for (int c = 0; c < V64; ++c)
+                *(float4 *)(part + (long long)row * V + 64 * c + 4 * lr) =
                     make_float4(acc[c * 4 + 0][r], acc[c * 4 + 1][r], acc[c * 4 + 2][r], acc[c * 4 + 3][r]);
         }
     }
@@ -170,6 +207,22 @@ __global__ __launch_bounds__(256) void moco_bwd_reduce_kernel(const float *part,
     for (int sl = 0; sl < nslices; ++sl) s += part[(long long)sl * b * D + e];
     const float ppos = __expf(lpos[row] * inv_t - lse[row]);
     dq[e] = grad_loss[0] * inv_t / (float)b * (s + (ppos - 1.f) * key[e]);
+}
+
+// probs_out[i][c] = alpha * probs_in[i][c] + (1 - alpha) * (sum_s part[s][i][c]) / (sum_s part[s][i][C])
+__global__ __launch_bounds__(256) void soft_knn_reduce_kernel(const float *part, int nslices, int b, int V, int C,
+                                                              const float *probs_in, float alpha, float *probs_out)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)b * C) return;
+    const int row = (int)(e / C), c = (int)(e - (long long)row * C);
+    float num = 0.f, den = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) {
+        const float *pr = part + ((long long)sl * b + row) * V;
+        num += pr[c];
+        den += pr[C];
+    }
+    probs_out[e] = alpha * probs_in[e] + (1.f - alpha) * (num / den);
 }
 
 // Ring-buffer enqueue that first saves the rows it overwrites (16-byte units).

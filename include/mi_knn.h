@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -155,6 +155,17 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
                 int64_t D, float temperature, const float *lse, const float *lpos,
                 const float *grad_loss, float *dq,
                 const float *patch_rows, int64_t patch_lo, int64_t patch_n,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* CoMatch soft-kNN pseudo-label smoothing.  Replaces track_semi/comatch.py:187-189:
+ *   A = exp(feature @ bank_feature^T / T) ; A = A / A.sum(1) ; probs_out = alpha*probs_in + (1-alpha) * A @ bank_prob
+ * (plain exp without max subtraction, as the reference) without writing the [b, K] matrix A.
+ * feature [b, D], bank_feature [K, D], bank_prob [K, C], probs_in/probs_out [b, C], all float32 row-major.
+ * D % 64 == 0, 1 <= C <= 255, and the tiles must fit the 160 KiB LDS: D <= 128 with any C, D = 192 with
+ * C <= 127 (MI_ERR_UNSUPPORTED otherwise; the reference's feature_dim is 64). */
+size_t mi_soft_knn_workspace_bytes(int64_t b, int64_t K, int64_t D, int64_t C);
+int mi_soft_knn(const float *feature, const float *bank_feature, const float *bank_prob, const float *probs_in,
+                int64_t b, int64_t K, int64_t D, int64_t C, float temperature, float alpha, float *probs_out,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* mi_queue_push that first copies the rows it overwrites to stash[0 .. w) (w = rows written):

@@ -22,6 +22,7 @@ Reference lines followed (all under /root/reference):
   * ``models/memory_bank.py:14-32``  StorageBank                     -> :class:`StorageBankOracle`
   * ``models/memory_bank.py:43-72``  MemoryBank (truncating ring)    -> :class:`MemoryBankOracle`
   * ``models/module_utils.py:48-148`` wrapping MemoryBank / LongTensorMemoryBank -> :class:`WrappingQueueOracle`
+  * ``track_semi/comatch.py:187-189`` soft-kNN pseudo-label smoothing        -> :func:`comatch_smooth_prob`
   * ``track_ssl/ssltrainer.py:166-190`` harness (normalise, transpose, column-0 accuracy)
                                                                      -> :func:`knn_monitor_accuracy`
   * ``track_ssl/moco.py:103-106,152-163`` queue init / logits / push-before-backward
@@ -242,6 +243,16 @@ def ring_push_plan(ptr: int, K: int, b: int):
     """(rows actually written, new pointer) of one truncating push -- memory_bank.py:65-72."""
     w = min(b, K - ptr)
     return w, (ptr + w) % K
+
+
+# --------------------------------------------------------------------------- CoMatch smoothing (track_semi/comatch.py)
+def comatch_smooth_prob(un_w_feature, mb_feature, mb_prob, un_w_probs, temperature, alpha, dtype=F32):
+    """comatch.py:187-189 -- A = exp(f @ bank^T / T) (no max subtraction), row-normalised;
+    probs = alpha * p + (1 - alpha) * A @ bank_prob.  ``dtype=np.float64`` gives the tolerance reference."""
+    f, bf = np.asarray(un_w_feature, dtype), np.asarray(mb_feature, dtype)
+    A = np.exp((f @ bf.T) / dtype(temperature)).astype(dtype)
+    A = A / A.sum(axis=1, keepdims=True)
+    return (dtype(alpha) * np.asarray(un_w_probs, dtype) + dtype(1 - alpha) * (A @ np.asarray(mb_prob, dtype))).astype(dtype)
 
 
 # --------------------------------------------------------------------------- MoCo queue (track_ssl/moco.py)

@@ -250,7 +250,32 @@ def wrapping_queue_cases():
     _save("wrapping_queue", **out)
 
 
+def comatch_smooth_cases():
+    """track_semi/comatch.py:185-189 is a closure inside CoMatchTrainer.train_step (needs lumo's Trainer: not
+    importable).  Its three torch expressions are evaluated here verbatim on torch CPU; only data is stored."""
+    out = {}
+    for tag, (b, K, D, C, T, alpha, seed) in {
+        "cifar10": (448, 1792, 64, 10, 0.2, 0.9, 0),          # batch 64 x mu 7, feature_dim 64
+        "cifar100": (192, 1500, 64, 100, 0.2, 0.9, 1),
+        "ragged": (37, 333, 128, 7, 0.1, 0.5, 2),
+    }.items():
+        g = torch.Generator().manual_seed(seed)
+        un_w_featrure = torch.nn.functional.normalize(torch.randn(b, D, generator=g), dim=-1)
+        mb_feature = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=-1)
+        mb_feature[: b // 2] = torch.nn.functional.normalize(un_w_featrure[: b // 2] + 0.1 * torch.randn(b // 2, D, generator=g), dim=-1)
+        mb_prob = torch.softmax(3 * torch.randn(K, C, generator=g), dim=1)
+        un_w_probs = torch.softmax(2 * torch.randn(b, C, generator=g), dim=1)
+        A = torch.exp(torch.mm(un_w_featrure, mb_feature.t()) / T)                       # comatch.py:187
+        A = A / A.sum(1, keepdim=True)                                                   # comatch.py:188
+        probs = alpha * un_w_probs + (1 - alpha) * torch.mm(A, mb_prob)                  # comatch.py:189
+        out.update({f"{tag}_feature": un_w_featrure.numpy(), f"{tag}_mb_feature": mb_feature.numpy(),
+                    f"{tag}_mb_prob": mb_prob.numpy(), f"{tag}_probs_in": un_w_probs.numpy(),
+                    f"{tag}_probs_out": probs.numpy(), f"{tag}_T_alpha": np.array([T, alpha], np.float64)})
+    _save("comatch_smooth", **out)
+
+
 if __name__ == "__main__":
+    comatch_smooth_cases()
     knn_cases()
     bank_cases()
     wrapping_queue_cases()

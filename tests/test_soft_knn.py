@@ -1,0 +1,72 @@
+"""CoMatch soft-kNN smoothing (track_semi/comatch.py:187-189).
+
+Golden vectors = the reference's three torch expressions evaluated on torch CPU (the closure itself needs lumo's
+Trainer and cannot be imported; tests/golden/make_golden.py::comatch_smooth_cases).  Floating point: 1e-5 relative
+(+1e-7 absolute) -- float32 GEMM in a different summation order, exp in float32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_oracle as ko
+from tests import parity as P
+
+TAGS = ["cifar10", "cifar100", "ragged"]
+RTOL, ATOL = 1e-5, 1e-7
+
+
+def _case(tag):
+    z = np.load(P.GOLDEN + "/comatch_smooth.npz")
+    T, alpha = [float(v) for v in z[f"{tag}_T_alpha"]]
+    return {k: z[f"{tag}_{k}"] for k in ("feature", "mb_feature", "mb_prob", "probs_in", "probs_out")}, T, alpha
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_matches_reference_expressions(tag):
+    c, T, alpha = _case(tag)
+    got = ko.comatch_smooth_prob(c["feature"], c["mb_feature"], c["mb_prob"], c["probs_in"], T, alpha)
+    assert np.allclose(got, c["probs_out"], rtol=RTOL, atol=ATOL)
+    assert np.allclose(got.sum(1), 1.0, atol=1e-5)                     # a convex combination of distributions
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_hip_matches_reference_expressions(tag):
+    import image_classification_amd as ica
+    c, T, alpha = _case(tag)
+    d = lambda a: torch.from_numpy(a).cuda()
+    got = ica.smooth_prob(d(c["feature"]), d(c["mb_feature"]), d(c["mb_prob"]), d(c["probs_in"]), T, alpha).cpu().numpy()
+    assert np.allclose(got, c["probs_out"], rtol=RTOL, atol=ATOL), np.max(np.abs(got - c["probs_out"]))
+    ref64 = ko.comatch_smooth_prob(c["feature"], c["mb_feature"], c["mb_prob"], c["probs_in"], T, alpha, dtype=np.float64)
+    assert np.allclose(got, ref64, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,K,D,C", [(448, 14336, 64, 10), (1, 64, 64, 1), (130, 1000, 192, 100), (200, 4097, 128, 255), (64, 300, 64, 191)])
+def test_hip_shapes_vs_float64_oracle(b, K, D, C):
+    import image_classification_amd as ica
+    rs = np.random.RandomState(b + K + C)
+    f, bf = ko.l2_normalize(rs.randn(b, D)), ko.l2_normalize(rs.randn(K, D))
+    bp = rs.dirichlet(np.ones(C), size=K).astype(np.float32)
+    p = rs.dirichlet(np.ones(C), size=b).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    a = ica.smooth_prob(d(f), d(bf), d(bp), d(p), 0.2, 0.9)
+    b2 = ica.smooth_prob(d(f), d(bf), d(bp), d(p), 0.2, 0.9)
+    assert torch.equal(a, b2)                                           # deterministic
+    ref = ko.comatch_smooth_prob(f, bf, bp, p, 0.2, 0.9, dtype=np.float64)
+    assert np.allclose(a.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.gpu
+def test_hip_rejects_what_it_cannot_do():
+    import image_classification_amd as ica
+    z = lambda *s: torch.zeros(*s).cuda()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ica.smooth_prob(torch.zeros(2, 64), z(8, 64), z(8, 3), z(2, 3), 0.2, 0.9)
+    with pytest.raises(ValueError):
+        ica.smooth_prob(z(2, 64), z(8, 64), z(8, 3), z(2, 4), 0.2, 0.9)
+    with pytest.raises(ica._lib.MiKnnError):
+        ica.smooth_prob(z(2, 96), z(8, 96), z(8, 3), z(2, 3), 0.2, 0.9)      # D not a multiple of 64
+    with pytest.raises(ValueError):
+        ica.smooth_prob(z(2, 64), z(8, 64), z(8, 300), z(2, 300), 0.2, 0.9)  # C > 255
+    with pytest.raises(ica._lib.MiKnnError, match="LDS"):
+        ica.smooth_prob(z(2, 256), z(8, 256), z(8, 10), z(2, 10), 0.2, 0.9)  # D = 256 does not fit beside the value tile
