@@ -10,6 +10,7 @@ from .knn import BankBuilder, BankIndex, knn_merge, knn_predict, knn_predict_ful
 from .memory_bank import MemoryBank, StorageBank
 from .moco import contrastive_loss2, moco_queue_loss
 from .soft_knn import smooth_prob
+from .neighbors import kth_largest, neighbor_label_agreement
 
 __all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
-           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "smooth_prob", "sharded", "module_utils", "_lib"]
+           "pack_rows", "MemoryBank", "StorageBank", "contrastive_loss2", "moco_queue_loss", "smooth_prob", "kth_largest", "neighbor_label_agreement", "sharded", "module_utils", "_lib"]

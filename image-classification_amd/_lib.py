@@ -12,12 +12,12 @@ LIB_PATH = os.environ.get("MI_KNN_LIB") or os.path.join(HERE, "libmi_knn.so")   
 
 MI_F32, MI_BF16 = 0, 1
 MI_MAX_K, MI_MAX_CLASSES = 1024, 65536
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes",
     "mi_knn_topk", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
-    "mi_moco_fwd", "mi_moco_bwd", "mi_queue_push_stash", "mi_bank_append_normalized", "mi_queue_push_wrap", "mi_soft_knn_workspace_bytes", "mi_soft_knn",
+    "mi_moco_fwd", "mi_moco_bwd", "mi_queue_push_stash", "mi_bank_append_normalized", "mi_queue_push_wrap", "mi_soft_knn_workspace_bytes", "mi_soft_knn", "mi_kth_largest",
 ]
 
 
@@ -64,6 +64,8 @@ def lib() -> ctypes.CDLL:
     L.mi_soft_knn_workspace_bytes.argtypes = [i64, i64, i64, i64]
     L.mi_soft_knn.restype = i32
     L.mi_soft_knn.argtypes = [p, p, p, p, i64, i64, i64, i64, f32, f32, p, p, sz, p]
+    L.mi_kth_largest.restype = i32
+    L.mi_kth_largest.argtypes = [p, i64, i64, p, p]
     L.mi_bank_scatter.restype = i32
     L.mi_bank_scatter.argtypes = [p, i64, i64, p, p, i64, p]
     L.mi_moco_workspace_bytes.restype = sz

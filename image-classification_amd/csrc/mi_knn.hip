@@ -606,6 +606,16 @@ int mi_knn_merge(const float *cand_val, const int64_t *cand_idx, int G, int64_t 
     return MI_OK;
 }
 
+int mi_kth_largest(const float *x, int64_t n, int64_t k, float *out, mi_stream_t stream)
+{
+    if (!x || !out) return fail(MI_ERR_ARG, "mi_kth_largest: null pointer");
+    if (n < 1 || n > INT32_MAX) return fail(MI_ERR_ARG, "mi_kth_largest: n=%lld outside [1, 2^31)", (long long)n);
+    if (k < 1 || k > n) return fail(MI_ERR_ARG, "mi_kth_largest: selected index k out of range (k=%lld, n=%lld)", (long long)k, (long long)n);
+    hipLaunchKernelGGL(mi::kth_largest_kernel, dim3(1), dim3(mi::KTH_THREADS), 0, (hipStream_t)stream, x, (long long)n, (long long)k, out);
+    HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
 int mi_knn_vote(const float *val, const int64_t *idx, const int64_t *labels, int64_t n_labels,
                 int64_t B, int k, int classes, float knn_t,
                 float *out_scores, int64_t *out_rank, mi_stream_t stream)

@@ -293,4 +293,50 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
     }
 }
 
+// k-th largest value of a 1-D float bank (track_semi/chmatch.py:252,294: `bank.topk(k)[0][-1]`, k up to 0.8 n):
+// MSB-first radix select over the order-preserving key of every element, 4 passes of 8 bits, one workgroup
+// (the bank is 50 000 floats: 200 KB, L2 resident; the kernel is latency-, not bandwidth-bound).  Selection
+// only: the result is one of the inputs, bit for bit.  NaNs order above +inf, as torch.topk does.
+constexpr int KTH_THREADS = 1024;
+__global__ __launch_bounds__(KTH_THREADS) void kth_largest_kernel(const float *__restrict__ x, long long n, long long k,
+                                                                 float *__restrict__ out)
+{
+    __shared__ unsigned hist[KTH_THREADS / 64][256];          // one histogram per wave: fewer LDS atomic collisions
+    __shared__ unsigned s_prefix;
+    __shared__ long long s_rank;
+    const int tid = threadIdx.x, wv = tid >> 6;
+    if (tid == 0) { s_prefix = 0u; s_rank = k; }
+    unsigned mask = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = tid; i < (KTH_THREADS / 64) * 256; i += KTH_THREADS) (&hist[0][0])[i] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (long long i = tid; i < n; i += KTH_THREADS) {
+            const float v = x[i];
+            const unsigned key = (v != v) ? 0xFFFFFFFFu : orderable_f32(v);
+            if ((key & mask) == prefix) atomicAdd(&hist[wv][(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {                                       // fold the per-wave histograms
+            unsigned c = 0u;
+            for (int w2 = 0; w2 < KTH_THREADS / 64; ++w2) c += hist[w2][tid];
+            hist[0][tid] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long rank = s_rank, cum = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[0][b] >= rank) break;
+                cum += hist[0][b];
+            }
+            s_rank = rank - cum;
+            s_prefix = prefix | ((unsigned)b << shift);
+        }
+        mask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = s_prefix == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : from_orderable(s_prefix);
+}
+
 }  // namespace mi

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -96,6 +96,12 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
  *      every valid index < 2^32. */
 int mi_knn_merge(const float *cand_val, const int64_t *cand_idx, int G, int64_t B, int kc, int k,
                  float *out_val, int64_t *out_idx, mi_stream_t stream);
+
+/* k-th largest value of a 1-D float32 bank.  Replaces track_semi/chmatch.py:252-253 and :294-295
+ * (`thresh, _ = mem['fine'].topk(int(k)); thresh[-1]`, a 50 000-score bank, k up to 0.8 n): MSB-first radix
+ * select, no sort, result = one of the inputs bit for bit (NaN orders above +inf, as torch.topk).
+ * out: device float32[1].  1 <= k <= n < 2^31. */
+int mi_kth_largest(const float *x, int64_t n, int64_t k, float *out, mi_stream_t stream);
 
 /* Label gather + exp(s/T) weights + per-class vote + full class ranking.
  * Replaces models/knn.py:10-20 (gather, div/exp, one-hot scatter, weighted sum, argsort).

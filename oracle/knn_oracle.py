@@ -255,6 +255,26 @@ def comatch_smooth_prob(un_w_feature, mb_feature, mb_prob, un_w_probs, temperatu
     return (dtype(alpha) * np.asarray(un_w_probs, dtype) + dtype(1 - alpha) * (A @ np.asarray(mb_prob, dtype))).astype(dtype)
 
 
+# --------------------------------------------------------------------------- order statistic / small-k sites
+def kth_largest(bank, k: int):
+    """chmatch.py:252-253,294-295 -- ``bank.topk(int(k))[0][-1]``: the k-th largest entry of a 1-D bank."""
+    x = np.asarray(bank, F32)
+    if k < 1 or k > x.size:
+        raise ValueError("selected index k out of range")
+    return np.sort(x)[::-1][k - 1]
+
+
+def neighbor_label_agreement(feature, mb_feature, mb_pred, noisy_labels, k=10, eps=1e-8):
+    """betacs_v2.py:159-162 -- cosine similarity (PARITY UNPINNED: lumo's batch_cosine_similarity2 is absent;
+    a.b / (max(|a|, eps) max(|b|, eps))), top-k, neighbours' argmax label, agreement count with the noisy label."""
+    a, b = np.asarray(feature, np.float64), np.asarray(mb_feature, np.float64)
+    an = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), eps)
+    bn = b / np.maximum(np.linalg.norm(b, axis=1, keepdims=True), eps)
+    vals, idx = topk_desc((an @ bn.T).astype(F32), k)
+    lbl = np.asarray(mb_pred)[idx].argmax(axis=-1)
+    return (np.asarray(noisy_labels)[:, None] == lbl).sum(axis=-1), vals, idx
+
+
 # --------------------------------------------------------------------------- MoCo queue (track_ssl/moco.py)
 def moco_queue_init(K: int, D: int, rng=None) -> np.ndarray:
     """moco.py:103-106 -- rows of U[0,1) noise, L2-normalised."""

@@ -274,7 +274,33 @@ def comatch_smooth_cases():
     _save("comatch_smooth", **out)
 
 
+def kth_threshold_cases():
+    """track_semi/chmatch.py:252-253 (`thresh, _ = self.mem['fine'].topk(int(k)); thresh[-1]`) evaluated verbatim by
+    torch CPU on score banks of the reference's size (mlen 50 000, chmatch.py:37) -- a closure in a lumo Trainer,
+    so the expression is executed here, not imported."""
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    banks = {
+        "rand": torch.rand(50000, generator=g),                                       # MemoryBank.register init
+        "scores": torch.softmax(4 * torch.randn(50000, 10, generator=g), dim=1).max(dim=1).values,
+        "ties": (torch.randint(0, 50, (50000,), generator=g).float() / 50.0),
+        "small": torch.randn(7, generator=g),
+    }
+    for name, fine in banks.items():
+        n = fine.numel()
+        ks = sorted({1, 2, n // 10 + 1, n // 2, int(0.8 * n), n})
+        res = []
+        for k in ks:
+            thresh, _ = fine.topk(int(k))
+            res.append(float(thresh[-1]))
+        out[f"{name}_bank"] = fine.numpy()
+        out[f"{name}_ks"] = np.array(ks, np.int64)
+        out[f"{name}_thresh"] = np.array(res, np.float32)
+    _save("kth_threshold", **out)
+
+
 if __name__ == "__main__":
+    kth_threshold_cases()
     comatch_smooth_cases()
     knn_cases()
     bank_cases()

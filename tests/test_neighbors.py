@@ -1,0 +1,82 @@
+"""the k-th-largest threshold of chmatch.py:252-253,294-295 and the small-k neighbour filter of
+betacs_v2.py:159-163.  Integer / selection work is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_oracle as ko
+from tests import parity as P
+
+BANKS = ["rand", "scores", "ties", "small"]
+
+
+def _z():
+    return np.load(P.GOLDEN + "/kth_threshold.npz")
+
+
+@pytest.mark.parametrize("name", BANKS)
+def test_oracle_kth_matches_reference_expression(name):
+    z = _z()
+    for k, t in zip(z[f"{name}_ks"], z[f"{name}_thresh"]):
+        assert ko.kth_largest(z[f"{name}_bank"], int(k)) == t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BANKS)
+def test_hip_kth_matches_reference_expression(name):
+    import image_classification_amd as ica
+    z = _z()
+    bank = torch.from_numpy(z[f"{name}_bank"]).cuda()
+    for k, t in zip(z[f"{name}_ks"], z[f"{name}_thresh"]):
+        got = ica.kth_largest(bank, int(k))
+        assert got.dim() == 0 and got.item() == t, (name, k)
+
+
+@pytest.mark.gpu
+def test_hip_kth_edge_cases():
+    import image_classification_amd as ica
+    x = np.array([0.5, -0.0, 0.0, -3.0, np.inf, -np.inf, 2.0, np.nan], np.float32)
+    t = torch.from_numpy(x).cuda()
+    ref = torch.from_numpy(x).topk(8).values.numpy()                   # torch: NaN first, then descending
+    for k in range(1, 9):
+        got = ica.kth_largest(t, k).item()
+        assert (np.isnan(got) and np.isnan(ref[k - 1])) or got == ref[k - 1], (k, got, ref[k - 1])
+    rs = np.random.RandomState(0)
+    big = rs.randn(1_000_003).astype(np.float32)
+    assert ica.kth_largest(torch.from_numpy(big).cuda(), 800_000).item() == ko.kth_largest(big, 800_000)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ica.kth_largest(t, 9)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ica.kth_largest(torch.from_numpy(x), 1)
+    # the caller's use (chmatch.py:252-254): threshold then mask, on a MemoryBank 1-D queue
+    mem = ica.MemoryBank()
+    mem.register("fine", -1, 50000)
+    mem = mem.cuda()
+    scores = torch.rand(448, device="cuda")
+    before = mem["fine"].cpu().numpy().copy()
+    thresh = ica.kth_largest(mem["fine"], int(0.8 * 50000))            # threshold from the bank BEFORE the push
+    mem.push("fine", scores)
+    assert thresh.item() == ko.kth_largest(before, int(0.8 * 50000))
+    assert scores.ge(thresh).dtype == torch.bool
+
+
+@pytest.mark.gpu
+def test_hip_neighbor_label_agreement_vs_oracle():
+    """betacs_v2.py:159-162 with the fused top-k at k = 10 (cosine definition: parity unpinned, see neighbors.py)."""
+    import image_classification_amd as ica
+    rs = np.random.RandomState(4)
+    b, K, D, C = 300, 20000, 128, 10
+    cent = rs.randn(C, D)
+    mb_lab = rs.randint(0, C, size=K)
+    mb_feature = (cent[mb_lab] + 0.8 * rs.randn(K, D)).astype(np.float32) * rs.uniform(0.5, 4.0, size=(K, 1)).astype(np.float32)
+    mb_pred = rs.dirichlet(np.ones(C) * 0.3, size=K).astype(np.float32)
+    nys = rs.randint(0, C, size=b)
+    w_feature = (cent[nys] + 0.8 * rs.randn(b, D)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    eq, val, idx = ica.neighbor_label_agreement(d(w_feature), d(mb_feature), d(mb_pred), d(nys), k=10, eps=1e-8)
+    eq_ref, val_ref, idx_ref = ko.neighbor_label_agreement(w_feature, mb_feature, mb_pred, nys, k=10, eps=1e-8)
+    assert np.max(np.abs(val.cpu().numpy() - val_ref)) <= 2e-6
+    same = np.array([set(a) == set(b_) for a, b_ in zip(idx.cpu().numpy().tolist(), idx_ref.tolist())])
+    assert same.mean() >= 0.98                                         # 10th/11th neighbour within rounding may swap
+    assert np.array_equal(eq.cpu().numpy()[same], eq_ref[same])
+    assert eq.dtype == torch.int64 and tuple(eq.shape) == (b,)
