@@ -85,10 +85,110 @@ struct SelectParams {
     int parity;
 };
 
+// LDS of one select workgroup.
+constexpr int SORT_OUT = 1024;        // >= MI_MAX_K: the kept keys are sorted here
+struct SelectSmem {
+    unsigned long long keys[SORT_P];  // current top-k + one batch of new candidates (unsorted)
+    unsigned long long out[SORT_OUT]; // the kept keys, compacted, then sorted
+    unsigned hist[256];
+    unsigned long long red[2 * (SEL_THREADS / 64)];
+    unsigned long long kth;
+    int bin, rank, bin_count, count;
+};
+
+__device__ __forceinline__ unsigned long long wave_and64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v &= __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// The rank-th largest (1-based) of the NON-ZERO keys in keys[0, tot) (at least `rank` of them, all distinct):
+// MSB-first radix select, 8 bits per pass, starting at the highest bit in which the keys differ at all (so
+// the exponent bits that similarities share cost no pass and no histogram hot spot) and stopping as soon as
+// the selected bin holds one key.  Every thread returns the same value.  A full sort of 2048 keys took
+// ~80 us per row; this plus sorting only the kept keys takes ~1/5 of that.
+__device__ __forceinline__ unsigned long long radix_select_kth(SelectSmem &sm, int tot, int rank, int tid)
+{
+    unsigned long long a = ~0ull, o = 0ull;
+    for (int i = tid; i < tot; i += SEL_THREADS) {
+        const unsigned long long key = sm.keys[i];
+        if (key) { a &= key; o |= key; }
+    }
+    a = wave_and64(a);
+    o = wave_or64(o);
+    if ((tid & 63) == 0) { sm.red[2 * (tid >> 6)] = a; sm.red[2 * (tid >> 6) + 1] = o; }
+    if (tid == 0) sm.rank = rank;
+    __syncthreads();
+    a = ~0ull; o = 0ull;
+#pragma unroll
+    for (int w = 0; w < SEL_THREADS / 64; ++w) { a &= sm.red[2 * w]; o |= sm.red[2 * w + 1]; }
+    const unsigned long long var = a ^ o;
+    if (var == 0ull) return a;                                   // a single distinct key
+    const int hb = 63 - __clzll((long long)var);
+    unsigned long long pmask = hb == 63 ? 0ull : ~((2ull << hb) - 1ull);     // bits every key shares
+    unsigned long long prefix = a & pmask;
+    for (int top = hb; top >= 0; top -= 8) {
+        const int sh = top >= 7 ? top - 7 : 0;
+        const unsigned dmask = top >= 7 ? 255u : ((1u << (top + 1)) - 1u);
+        sm.hist[tid] = 0u;                                       // SEL_THREADS == 256 bins
+        __syncthreads();
+        for (int i = tid; i < tot; i += SEL_THREADS) {
+            const unsigned long long key = sm.keys[i];
+            if (key && (key & pmask) == prefix) atomicAdd(&sm.hist[(unsigned)(key >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l .. 4l+3; suffix sums from the top bin down
+            const unsigned h0 = sm.hist[4 * tid], h1 = sm.hist[4 * tid + 1], h2 = sm.hist[4 * tid + 2], h3 = sm.hist[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned incl = mine;                                // sum over lanes >= this one
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned t = __shfl_down(incl, d, 64);
+                if (tid + d < 64) incl += t;
+            }
+            const unsigned above = incl - mine;                  // keys in bins of higher lanes
+            const unsigned r = (unsigned)sm.rank;
+            if (above < r && r <= incl) {                        // the rank-th largest falls into this lane's bins
+                unsigned acc = above;
+                int b = 4 * tid + 3;
+                unsigned hb_cnt = h3;
+                if (acc + h3 < r) { acc += h3; b = 4 * tid + 2; hb_cnt = h2;
+                    if (acc + h2 < r) { acc += h2; b = 4 * tid + 1; hb_cnt = h1;
+                        if (acc + h1 < r) { acc += h1; b = 4 * tid; hb_cnt = h0; } } }
+                sm.bin = b;
+                sm.rank = (int)(r - acc);
+                sm.bin_count = (int)hb_cnt;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)(unsigned)sm.bin << sh;
+        pmask |= (unsigned long long)dmask << sh;
+        if (sh == 0) break;
+        if (sm.bin_count == 1) {                                 // one key left under this prefix: it is the answer
+            for (int i = tid; i < tot; i += SEL_THREADS) {
+                const unsigned long long key = sm.keys[i];
+                if (key && (key & pmask) == prefix) sm.kth = key;
+            }
+            __syncthreads();
+            return sm.kth;
+        }
+    }
+    return prefix;
+}
+
 template <int SRC>
-__device__ __forceinline__ void select_row(const SelectParams &p, const int row, unsigned long long *keys, int &s_valid)
+__device__ __forceinline__ void select_row(const SelectParams &p, const int row, SelectSmem &sm)
 {
     const int tid = threadIdx.x;
+    unsigned long long *keys = sm.keys;
 
     int n_new;
     if constexpr (SRC == SRC_LIST) {
@@ -114,6 +214,7 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
     while (pos < n_new) {
         const int room = SORT_P - n_cur;
         const int m = (n_new - pos) < room ? (n_new - pos) : room;
+        int nz_mine = 0;
         for (int i = tid; i < m; i += SEL_THREADS) {
             const int e = pos + i;
             unsigned long long key;
@@ -130,27 +231,43 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
                 key = gi < 0 ? 0ull : make_key(p.g_val[off], (unsigned)gi);
             }
             keys[n_cur + i] = key;
+            nz_mine += key != 0ull;
         }
+        if (tid == 0) sm.count = 0;
+        __syncthreads();
+        // real (non-zero) keys in this batch; the kept keys of earlier passes are all real
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz_mine += __shfl_xor(nz_mine, d, 64);
+        if ((tid & 63) == 0 && nz_mine) atomicAdd(&sm.count, nz_mine);
+        __syncthreads();
         const int tot = n_cur + m;
+        const int nz = n_cur + sm.count;
+        const int keep = nz < p.k ? nz : p.k;
+        __syncthreads();                                          // sm.count is reused below
+        unsigned long long kth = 1ull;                            // nz <= k: keep every real key
+        if (nz > keep) kth = radix_select_kth(sm, tot, keep, tid);
+        if (tid == 0) sm.count = 0;
+        __syncthreads();
+        for (int i = tid; i < tot; i += SEL_THREADS) {
+            const unsigned long long key = keys[i];
+            if (key >= kth) {                                     // exactly `keep` keys: they are distinct
+                const int slot = atomicAdd(&sm.count, 1);
+                if (slot < SORT_OUT) sm.out[slot] = key;
+            }
+        }
         int n2 = 64;
-        while (n2 < tot) n2 <<= 1;
-        for (int i = tot + tid; i < n2; i += SEL_THREADS) keys[i] = 0ull;
+        while (n2 < keep) n2 <<= 1;
         __syncthreads();
-        bitonic_sort_desc(keys, n2, tid);
-        // keep the best k; empty (0) keys sort last, count how many of the kept ones are real
-        const int keep = tot < p.k ? tot : p.k;
-        if (tid == 0) s_valid = 0;
+        for (int i = keep + tid; i < n2; i += SEL_THREADS) sm.out[i] = 0ull;
         __syncthreads();
-        int mine = 0;
-        for (int i = tid; i < keep; i += SEL_THREADS) mine += keys[i] != 0ull;
-        if (mine) atomicAdd(&s_valid, mine);
-        __syncthreads();
-        n_cur = s_valid;
+        bitonic_sort_desc(sm.out, n2, tid);
+        for (int i = tid; i < keep; i += SEL_THREADS) keys[i] = sm.out[i];
+        n_cur = keep;
         pos += m;
         __syncthreads();
     }
-
     __syncthreads();
+
     if constexpr (SRC != SRC_GATHER) {
         for (int i = tid; i < n_cur; i += SEL_THREADS) p.topk[(long long)row * p.k + i] = keys[i];
         if (tid == 0) {
@@ -172,21 +289,20 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
 template <int SRC>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams p)
 {
-    __shared__ unsigned long long keys[SORT_P];
-    __shared__ int s_valid;
+    __shared__ SelectSmem sm;
     if constexpr (SRC == SRC_LIST) {
         if (p.big_rows) {
             // workgroup b serves sub-list b % BIG_SUBLISTS, every (gridDim / BIG_SUBLISTS)-th entry
             const unsigned sub = blockIdx.x & (BIG_SUBLISTS - 1), per = gridDim.x / BIG_SUBLISTS;
             const unsigned n = p.big_cnt[(p.parity * BIG_SUBLISTS + sub) * 32];
             for (unsigned i = blockIdx.x / BIG_SUBLISTS; i < n; i += per) {
-                select_row<SRC>(p, p.big_rows[(long long)sub * p.big_stride + i], keys, s_valid);
-                __syncthreads();                                   // keys / s_valid are reused by the next row
+                select_row<SRC>(p, p.big_rows[(long long)sub * p.big_stride + i], sm);
+                __syncthreads();                                   // the LDS is reused by the next row
             }
             return;
         }
     }
-    select_row<SRC>(p, blockIdx.x, keys, s_valid);
+    select_row<SRC>(p, blockIdx.x, sm);
 }
 
 // Wave-per-row merge: the common case after the first few stages is a handful of new candidates
