@@ -37,7 +37,7 @@ constexpr int KSTEP_BYTES = 128;          // bytes of one row per K-step
 constexpr int OPERAND_TILE_BYTES = TILE * KSTEP_BYTES;       // 32 KiB
 constexpr int STAGE_BYTES = 2 * OPERAND_TILE_BYTES;          // A + B
 constexpr int SIM_LDS_BYTES = 2 * STAGE_BYTES;               // double buffered: 128 KiB
-constexpr int SIM_EXTRA_LDS = 1024;                         // thresholds of the tile's 256 rows
+constexpr int SIM_EXTRA_LDS = 2048;                         // thresholds + candidate counters of the tile's 256 rows
 constexpr int LCAND = 32;                                  // LDS candidate slots per row and tile
 constexpr int SIM_THREADS = 512;
 constexpr int PATCH_Q = 8, PATCH_N = 4;   // tiles of one XCD patch (8 query tiles x 4 bank tiles)
@@ -194,7 +194,11 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 
     if constexpr (MODE == MODE_FILTER) {
         // thresholds of this tile's 256 query rows -> spare LDS (read back in the epilogue)
-        if (tid < TILE) ((float *)(smem + SIM_LDS_BYTES))[tid] = p.tau[q0 + tid];
+        // (the K loop's barriers publish them long before the epilogue reads them)
+        if (tid < TILE) {
+            ((float *)(smem + SIM_LDS_BYTES))[tid] = p.tau[q0 + tid];
+            ((unsigned *)(smem + SIM_LDS_BYTES + 1024))[tid] = 0u;
+        }
     }
 
     f32x4 acc[8][4];
@@ -368,11 +372,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         // then ONE global atomic per row reserves the row's list space and the row's entries are
         // copied out.  (Returning GLOBAL atomics per candidate serialise a wave: ~25/stage-index
         // candidates per wave and tile at ~1.5 us each cost 19 % of the kernel.)
-        unsigned *lcnt = (unsigned *)smem;                         // [256]
-        uint2 *llist = (uint2 *)(smem + 1024);                     // [256][LCAND]
+        unsigned *lcnt = (unsigned *)(smem + SIM_LDS_BYTES + 1024);   // [256] zeroed at kernel start
+        uint2 *llist = (uint2 *)smem;                              // [256][LCAND] over the (now idle) operand buffers
         const float *ltau = (const float *)(smem + SIM_LDS_BYTES); // [256] staged at kernel start
-        if (tid < TILE) lcnt[tid] = 0u;
-        __syncthreads();
         f32x4 tau[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) tau[i] = *(const f32x4 *)(ltau + wm * 128 + lq * 4 + i * 16);
@@ -384,10 +386,10 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float t = tau[i][r];
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) any |= (colok[j] && acc[i][j][r] >= t);
-                if (__any(any)) {
+                // one v_max3 + v_max + v_cmp per row instead of four masked compares: the column-validity
+                // test only matters in the (rare) slow path below.  NaNs never pass: max ignores them.
+                const float m = fmaxf(fmaxf(acc[i][0][r], acc[i][1][r]), fmaxf(acc[i][2][r], acc[i][3][r]));
+                if (__any(m >= t)) {
                     const int rl = wm * 128 + lq * 4 + i * 16 + r;        // row within the tile
                     if (q0 + rl < p.B) {
 #pragma unroll
