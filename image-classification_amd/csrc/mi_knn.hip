@@ -163,13 +163,14 @@ __global__ __launch_bounds__(256) void append_normalized_kernel(const float *__r
     for (int c = lane; c < (int)ld; c += 64) o[c] = (OutT)(c < D ? x[c] / denom : 0.f);
 }
 
-__global__ void init_state_kernel(float *tau, unsigned *cnt, int *topk_n, unsigned *big_cnt, int B, int B_pad)
+__global__ void init_state_kernel(float *tau, int *topk_n, unsigned *big_cnt, unsigned *tmask, int mask_words, int B, int B_pad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B_pad)
+        for (int j = 0; j < mask_words; ++j) tmask[(long long)i * mask_words + j] = 0u;
     if (i < 2 * mi::BIG_SUBLISTS) big_cnt[i * 32] = 0u;
     if (i < B_pad) {
         tau[i] = i < B ? -INFINITY : INFINITY;
-        cnt[i] = 0u;
         topk_n[i] = 0;
     }
 }
@@ -284,7 +285,8 @@ struct Plan {
     int s0_cols;        // dense bootstrap stage
     int min_cols;       // smallest useful filter stage (enough workgroups to fill the chip)
     int cap;            // candidate slots per row (>= every stage's columns: overflow impossible)
-    size_t off_tau, off_cnt, off_topkn, off_big, off_topk, off_cand, fixed, total;
+    size_t off_tau, off_topkn, off_big, off_topk, off_mask, off_cnt2, off_cand, fixed, total;
+    int mask_words;
 };
 
 #ifndef MI_S0_COLS
@@ -305,8 +307,10 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     pl.qtiles = pl.B_pad / mi::TILE;
     pl.s0_cols = (int)(N < S0_COLS ? N : S0_COLS);
     pl.min_cols = (int)round_up(ceil_div(768, pl.qtiles) * mi::TILE, STAGE_QUANTUM);
-    const int64_t row_bytes = (int64_t)pl.B_pad * 8;
-    int64_t cap = (cand_bytes < 0 ? CAND_BUDGET_BYTES : cand_bytes) / row_bytes / STAGE_QUANTUM * STAGE_QUANTUM;
+    // per stage column: 8 bytes of candidate slot per query row + the per-(tile, row) u16 counts (B_pad / 128)
+    // (+ one bit per (tile, row) in the tile masks: B_pad / 2048; rounded up into the 1024-byte slack)
+    const int64_t row_bytes = (int64_t)pl.B_pad * 8 + pl.B_pad / 128 + (pl.B_pad + 2047) / 2048;
+    int64_t cap = ((cand_bytes < 0 ? CAND_BUDGET_BYTES : cand_bytes) - 1024 - 4 * pl.B_pad) / row_bytes / STAGE_QUANTUM * STAGE_QUANTUM;
     int64_t useful = round_up(N > S0_COLS ? N - S0_COLS : S0_COLS, STAGE_QUANTUM);        // one stage for all the rest
     if (useful < S0_COLS) useful = S0_COLS;
     if (cap > useful) cap = useful;
@@ -323,11 +327,13 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (size_t)round_up((int64_t)(off + bytes), 256); return o; };
     pl.off_tau = take((size_t)pl.B_pad * 4);
-    pl.off_cnt = take((size_t)pl.B_pad * 4);
     pl.off_topkn = take((size_t)pl.B_pad * 4);
     pl.off_big = take((size_t)BIG_CNT_BYTES + (size_t)mi::BIG_SUBLISTS * big_stride(pl.B_pad) * 4);   // counters + row sub-lists
     pl.off_topk = take((size_t)pl.B_pad * k * 8);
     pl.fixed = off;
+    pl.mask_words = (int)ceil_div(pl.cap / mi::TILE, 32);
+    pl.off_mask = take((size_t)pl.B_pad * pl.mask_words * 4);
+    pl.off_cnt2 = take((size_t)(pl.cap / mi::TILE) * pl.B_pad * 2);
     pl.off_cand = take((size_t)pl.B_pad * pl.cap * 8);
     pl.total = off;
     return pl;
@@ -473,7 +479,7 @@ int mi_bank_append_normalized(const float *src, int64_t ld_src, int64_t b, int64
 size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k)
 {
     if (B <= 0 || N <= 0 || k <= 0 || k > MI_MAX_K || B > (1 << 30) || N > INT32_MAX - 2 * mi::TILE) return 0;
-    return make_plan(B, N, k, -1).total;
+    return make_plan(B, N, k, -1).total + 2048 + 4 * (size_t)round_up(B, mi::TILE);        // + the alignment slack make_plan reserves when it sizes from a byte count
 }
 
 int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
@@ -495,19 +501,20 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     const Plan pl = make_plan(B, N, k, workspace_bytes > fixed ? (int64_t)(workspace_bytes - fixed) : 0, ld * elt_bytes(dtype));
     if (pl.cap == 0 || workspace_bytes < pl.total)
         return fail(MI_ERR_WORKSPACE, "mi_knn_topk: workspace %zu is below the minimum %zu (recommended: mi_knn_topk_workspace_bytes)",
-                    workspace_bytes, fixed + (size_t)pl.B_pad * S0_COLS * 8);
+                    workspace_bytes, fixed + 2048 + 4 * (size_t)pl.B_pad + (size_t)S0_COLS * ((size_t)pl.B_pad * 8 + pl.B_pad / 128 + 1));
 
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     float *tau = (float *)(ws + pl.off_tau);
-    unsigned *cnt = (unsigned *)(ws + pl.off_cnt);
+    unsigned short *cnt2 = (unsigned short *)(ws + pl.off_cnt2);
+    unsigned *tmask = (unsigned *)(ws + pl.off_mask);
     int *topk_n = (int *)(ws + pl.off_topkn);
     unsigned long long *topk = (unsigned long long *)(ws + pl.off_topk);
     uint2 *cand = (uint2 *)(ws + pl.off_cand);
 
     unsigned *big_cnt = (unsigned *)(ws + pl.off_big);
     int *big_rows = (int *)(ws + pl.off_big + BIG_CNT_BYTES);
-    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, cnt, topk_n, big_cnt, (int)B, pl.B_pad);
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, topk_n, big_cnt, tmask, pl.mask_words, (int)B, pl.B_pad);
     HIP_CHECK(hipGetLastError());
 
     mi::SimParams sp{};
@@ -520,13 +527,19 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     sp.ksteps = (int)(ld * elt_bytes(dtype) / mi::KSTEP_BYTES);
     sp.qtiles = pl.qtiles;
     sp.tau = tau;
-    sp.cnt = cnt;
+    sp.cnt2 = cnt2;
+    sp.tmask = tmask;
+    sp.mask_words = pl.mask_words;
+    sp.bpad = pl.B_pad;
     sp.cand = cand;
     sp.cap = pl.cap;
 
     mi::SelectParams sel{};
     sel.cand = cand;
-    sel.cnt = cnt;
+    sel.cnt2 = cnt2;
+    sel.tmask = tmask;
+    sel.mask_words = pl.mask_words;
+    sel.bpad = pl.B_pad;
     sel.cap = pl.cap;
     sel.B = B;
     sel.topk = topk;
@@ -563,6 +576,7 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
         sp.col0 = (int)col;
         sp.ncols = (int)ncols;
         sp.ntiles = (int)ceil_div(ncols, mi::TILE);
+        sel.ntiles = sp.ntiles;
         {
             ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)ncols * (double)D, s);
             HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));

@@ -57,8 +57,11 @@ constexpr int MERGE_MAX_NEW = 64;     // rows with <= 64 new candidates take the
 
 struct SelectParams {
     // candidate sources
-    const uint2 *cand;          // SRC_LIST : [B_pad, cap] (value bits, row);  SRC_DENSE: float [B_pad][2*cap]
-    unsigned *cnt;              // SRC_LIST : [B_pad] candidate counts (reset to 0 here)
+    const uint2 *cand;          // SRC_LIST : [B_pad, cap] (value bits, row), bank tile t of the stage owns slots
+                                //            [256 t, 256 t + cnt2[t][row]) of a row;  SRC_DENSE: float [B_pad][2*cap]
+    const unsigned short *cnt2; // SRC_LIST : [ntiles, bpad] candidates per (bank tile of the stage, query row)
+    unsigned *tmask;            // SRC_LIST : [B_pad, mask_words] bit t set <=> cnt2[t][row] is valid and > 0 (cleared here)
+    int ntiles, bpad, mask_words;
     int cap;
     int dense_n, dense_col0;    // SRC_DENSE: n values per row, bank row of value 0
     const float *g_val;         // SRC_GATHER: [G, B, kc]
@@ -93,6 +96,7 @@ struct SelectSmem {
     unsigned hist[256];
     unsigned long long red[2 * (SEL_THREADS / 64)];
     unsigned long long kth;
+    int wsum[SEL_THREADS / 64];
     int bin, rank, bin_count, count;
 };
 
@@ -190,20 +194,12 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
     const int tid = threadIdx.x;
     unsigned long long *keys = sm.keys;
 
-    int n_new;
-    if constexpr (SRC == SRC_LIST) {
-        const unsigned c = p.cnt[row];
-        n_new = c < (unsigned)p.cap ? (int)c : p.cap;
-    } else if constexpr (SRC == SRC_DENSE) {
-        n_new = p.dense_n;
-    } else {
-        n_new = p.G * p.kc;
-    }
+    int n_new = 0;                                    // SRC_LIST: tiles still to consume (the counts are per tile)
+    if constexpr (SRC == SRC_LIST) n_new = p.ntiles;
+    else if constexpr (SRC == SRC_DENSE) n_new = p.dense_n;
+    else n_new = p.G * p.kc;
     const bool finalize = p.out_val != nullptr;
     if (n_new == 0 && !finalize) return;
-    if constexpr (SRC == SRC_LIST) {
-        if (p.skip_small && n_new <= MERGE_MAX_NEW) return;
-    }
 
     int n_cur = 0;
     if constexpr (SRC != SRC_GATHER) {
@@ -213,25 +209,59 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
     int pos = 0;
     while (pos < n_new) {
         const int room = SORT_P - n_cur;
-        const int m = (n_new - pos) < room ? (n_new - pos) : room;
+        int m, step;                                  // m keys appended, `pos` advances by step
         int nz_mine = 0;
-        for (int i = tid; i < m; i += SEL_THREADS) {
-            const int e = pos + i;
-            unsigned long long key;
-            if constexpr (SRC == SRC_LIST) {
-                const uint2 c = p.cand[(long long)row * p.cap + e];
-                key = make_key(__uint_as_float(c.x), c.y);
-            } else if constexpr (SRC == SRC_DENSE) {
-                const float *d = (const float *)p.cand + (long long)row * 2 * p.cap;
-                key = make_key(d[e], (unsigned)(p.dense_col0 + e));
-            } else {
-                const int g = e / p.kc, j = e - g * p.kc;
-                const long long off = ((long long)g * p.B + row) * p.kc + j;
-                const long long gi = p.g_idx[off];
-                key = gi < 0 ? 0ull : make_key(p.g_val[off], (unsigned)gi);
+        if constexpr (SRC == SRC_LIST) {
+            // take the longest run of tiles from `pos` (one tile per thread) whose candidates fit the room:
+            // block-wide inclusive scan of the per-tile counts (a tile holds <= 256, room >= 1024: progress)
+            const int t = pos + tid;
+            int c = 0;
+            if (t < n_new && ((p.tmask[(long long)row * p.mask_words + (t >> 5)] >> (t & 31)) & 1u))
+                c = (int)p.cnt2[(long long)t * p.bpad + row];
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d) incl += o;
             }
-            keys[n_cur + i] = key;
-            nz_mine += key != 0ull;
+            if ((tid & 63) == 63) sm.wsum[tid >> 6] = incl;
+            if (tid == 0) { sm.count = 0; sm.rank = 0; }
+            __syncthreads();
+            for (int w = 0; w < (tid >> 6); ++w) incl += sm.wsum[w];
+            const bool fits = t < n_new && incl <= room;
+            if (fits) {
+                atomicAdd(&sm.rank, 1);                              // tiles taken (a prefix: incl is monotone)
+                atomicMax(&sm.count, incl);                          // keys taken
+                const uint2 *seg = p.cand + (long long)row * p.cap + (long long)t * 256;
+                for (int e = 0; e < c; ++e) {
+                    const uint2 cd = seg[e];
+                    const unsigned long long key = make_key(__uint_as_float(cd.x), cd.y);
+                    keys[n_cur + incl - c + e] = key;
+                    nz_mine += key != 0ull;
+                }
+            }
+            __syncthreads();
+            m = sm.count;
+            step = sm.rank;
+            __syncthreads();
+        } else {
+            m = (n_new - pos) < room ? (n_new - pos) : room;
+            step = m;
+            for (int i = tid; i < m; i += SEL_THREADS) {
+                const int e = pos + i;
+                unsigned long long key;
+                if constexpr (SRC == SRC_DENSE) {
+                    const float *d = (const float *)p.cand + (long long)row * 2 * p.cap;
+                    key = make_key(d[e], (unsigned)(p.dense_col0 + e));
+                } else {
+                    const int g = e / p.kc, j = e - g * p.kc;
+                    const long long off = ((long long)g * p.B + row) * p.kc + j;
+                    const long long gi = p.g_idx[off];
+                    key = gi < 0 ? 0ull : make_key(p.g_val[off], (unsigned)gi);
+                }
+                keys[n_cur + i] = key;
+                nz_mine += key != 0ull;
+            }
         }
         if (tid == 0) sm.count = 0;
         __syncthreads();
@@ -263,17 +293,19 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
         bitonic_sort_desc(sm.out, n2, tid);
         for (int i = tid; i < keep; i += SEL_THREADS) keys[i] = sm.out[i];
         n_cur = keep;
-        pos += m;
+        pos += step;
         __syncthreads();
     }
     __syncthreads();
 
+    if constexpr (SRC == SRC_LIST) {
+        for (int i = tid; i < p.mask_words; i += SEL_THREADS) p.tmask[(long long)row * p.mask_words + i] = 0u;
+    }
     if constexpr (SRC != SRC_GATHER) {
         for (int i = tid; i < n_cur; i += SEL_THREADS) p.topk[(long long)row * p.k + i] = keys[i];
         if (tid == 0) {
             p.topk_n[row] = n_cur;
             p.tau[row] = (n_cur >= p.k) ? key_value(keys[p.k - 1]) : -INFINITY;
-            if constexpr (SRC == SRC_LIST) p.cnt[row] = 0u;
         }
     }
     if (finalize) {
@@ -319,10 +351,22 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.B) return;
-    const unsigned c = p.cnt[row];
+    __shared__ uint2 stage[4][MERGE_MAX_NEW];
     const bool finalize = p.out_val != nullptr;
     if (blockIdx.x == 0 && threadIdx.x < BIG_SUBLISTS && p.big_cnt)
         p.big_cnt[((p.parity ^ 1) * BIG_SUBLISTS + threadIdx.x) * 32] = 0u;                  // the next stage's counters
+    // this row's candidates: cnt2[t][row] of them in the segment of every bank tile t of the stage
+    const unsigned *tm = p.tmask + row * p.mask_words;
+    int mine = 0;
+    for (int t = lane; t < p.ntiles; t += 64)
+        if ((tm[t >> 5] >> (t & 31)) & 1u) mine += (int)p.cnt2[(long long)t * p.bpad + row];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    const unsigned c = (unsigned)__shfl(incl, 63, 64);
     if (c > (unsigned)MERGE_MAX_NEW) {
         // one returning atomic per row on one word saturates at ~88 per us (16384 rows: 187 us);
         // the rows are spread over 64 sub-lists instead, each with its own counter line
@@ -347,9 +391,24 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
         pk[j] = i < n_cur ? topk[i] : 0ull;
         shift[j] = 0;
     }
+    // gather the <= 64 candidates, one per lane, through a wave-private LDS patch (any order)
+    uint2 *st = stage[threadIdx.x >> 6];
+    if (mine) {
+        int o = incl - mine;
+        for (int t = lane; t < p.ntiles; t += 64) {
+            if (!((tm[t >> 5] >> (t & 31)) & 1u)) continue;
+            const int n = (int)p.cnt2[(long long)t * p.bpad + row];
+            const uint2 *seg = p.cand + row * p.cap + (long long)t * 256;
+            for (int e = 0; e < n; ++e) st[o++] = seg[e];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // same wave: LDS ops complete in order
+    if (c) {                                                           // consumed: the next stage starts from a clear mask
+        for (int i = lane; i < p.mask_words; i += 64) p.tmask[row * p.mask_words + i] = 0u;
+    }
     unsigned long long ck = 0ull;
     if (lane < n_new) {
-        const uint2 cd = p.cand[row * p.cap + lane];
+        const uint2 cd = st[lane];
         ck = make_key(__uint_as_float(cd.x), cd.y);
     }
     const int n_valid_new = __popcll(__ballot(ck != 0ull));
@@ -383,10 +442,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
             if (np == k - 1) p.tau[row] = key_value(pk[j]);
         }
     }
-    if (lane == 0) {
-        p.topk_n[row] = n_out;
-        p.cnt[row] = 0u;
-    }
+    if (lane == 0) p.topk_n[row] = n_out;
     if (finalize) {
         // positions are final; emit (value, index) for every slot of this row from the merged keys
 #pragma unroll

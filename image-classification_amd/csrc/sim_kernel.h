@@ -38,7 +38,6 @@ constexpr int OPERAND_TILE_BYTES = TILE * KSTEP_BYTES;       // 32 KiB
 constexpr int STAGE_BYTES = 2 * OPERAND_TILE_BYTES;          // A + B
 constexpr int SIM_LDS_BYTES = 2 * STAGE_BYTES;               // double buffered: 128 KiB
 constexpr int SIM_EXTRA_LDS = 2048;                         // thresholds + candidate counters of the tile's 256 rows
-constexpr int LCAND = 32;                                  // LDS candidate slots per row and tile
 constexpr int SIM_THREADS = 512;
 constexpr int PATCH_Q = 8, PATCH_N = 4;   // tiles of one XCD patch (8 query tiles x 4 bank tiles)
 
@@ -56,8 +55,11 @@ struct SimParams {
     int pq, pn, qsh;          // patches of (1 << qsh) query tiles x (32 >> qsh) bank tiles (set by the launcher)
     // MODE_DENSE / MODE_FILTER
     const float *tau;         // [B_pad]  (+inf on padding rows)
-    unsigned *cnt;            // [B_pad]  per-row candidate count
-    uint2 *cand;              // [B_pad, cap] (value bits, bank row); dense mode: float[B_pad][2*cap]
+    unsigned short *cnt2;     // MODE_FILTER: [stage tiles, B_pad] candidates of (bank tile, query row)
+    unsigned *tmask;          // MODE_FILTER: [B_pad, mask_words] bit t set: bank tile t holds candidates of the row
+    int bpad, mask_words;
+    uint2 *cand;              // [B_pad, cap] (value bits, bank row): bank tile t of the stage owns slots
+                              // [256 t, 256 t + 256) of every row; dense mode: float[B_pad][2*cap]
     int cap;
     // MODE_LSE
     float inv_t;
@@ -364,17 +366,18 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
-            if (sum == 12345.678f) p.cnt[row_base] = 1u;
+            if (sum == 12345.678f) p.cnt2[0] = 1;
             return;
         }
 #endif
-        // Candidates are staged in LDS (free after the K loop): an LDS atomic hands out the slot,
-        // then ONE global atomic per row reserves the row's list space and the row's entries are
-        // copied out.  (Returning GLOBAL atomics per candidate serialise a wave: ~25/stage-index
-        // candidates per wave and tile at ~1.5 us each cost 19 % of the kernel.)
+        // Survivors go straight to HBM with NO global atomic: bank tile nt owns slots [256 nt, 256 nt + 256) of
+        // every row's candidate list (cap >= the stage's columns, so the segment always exists and can never
+        // overflow), an LDS atomic hands out the slot inside the segment, and the tile ends by storing its 256
+        // per-row counts as one contiguous block.  (History: returning GLOBAL atomics per candidate serialised
+        // a wave, -19 %; an LDS-staged list flushed through one returning global atomic per row still kept
+        // the workgroup -- and its 129 KiB of LDS -- alive for the atomic's round trip at the end of every tile.)
         unsigned *lcnt = (unsigned *)(smem + SIM_LDS_BYTES + 1024);   // [256] zeroed at kernel start
-        uint2 *llist = (uint2 *)smem;                              // [256][LCAND] over the (now idle) operand buffers
-        const float *ltau = (const float *)(smem + SIM_LDS_BYTES); // [256] staged at kernel start
+        const float *ltau = (const float *)(smem + SIM_LDS_BYTES);    // [256] staged at kernel start
         f32x4 tau[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) tau[i] = *(const f32x4 *)(ltau + wm * 128 + lq * 4 + i * 16);
@@ -392,36 +395,25 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 if (__any(m >= t)) {
                     const int rl = wm * 128 + lq * 4 + i * 16 + r;        // row within the tile
                     if (q0 + rl < p.B) {
+                        uint2 *seg = p.cand + (long long)(q0 + rl) * p.cap + (long long)nt * TILE;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float v = acc[i][j][r];
-                            if (colok[j] && v >= t) {
-                                const uint2 e = make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));
-                                const unsigned sl = atomicAdd(lcnt + rl, 1u);
-                                if (sl < (unsigned)LCAND) {
-                                    llist[rl * LCAND + sl] = e;
-                                } else {                                    // LDS list full: straight to HBM
-                                    const unsigned slot = atomicAdd(p.cnt + q0 + rl, 1u);
-                                    if (slot < (unsigned)p.cap) p.cand[(long long)(q0 + rl) * p.cap + slot] = e;
-                                }
-                            }
+                            if (colok[j] && v >= t)
+                                seg[atomicAdd(lcnt + rl, 1u)] = make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));
                         }
                     }
                 }
             }
 #if defined(MI_ABLATE) && (MI_ABLATE & 1024)
-        return;                                                     // timing-only: no flush of the LDS lists
+        return;                                                     // timing-only: no per-tile counts
 #endif
         __syncthreads();
         if (tid < TILE) {
-            unsigned n = lcnt[tid];
-            n = n < (unsigned)LCAND ? n : (unsigned)LCAND;
-            if (n) {
-                const long long row = q0 + tid;
-                const unsigned base = atomicAdd(p.cnt + row, n);
-                for (unsigned e = 0; e < n; ++e)
-                    if (base + e < (unsigned)p.cap) p.cand[row * p.cap + base + e] = llist[tid * LCAND + e];
-            }
+            const unsigned n = lcnt[tid];
+            p.cnt2[(long long)nt * p.bpad + q0 + tid] = (unsigned short)n;           // one contiguous block per tile
+            // which tiles to look at, per row: a no-return atomic (nothing waits for it)
+            if (n) atomicOr(p.tmask + (long long)(q0 + tid) * p.mask_words + (nt >> 5), 1u << (nt & 31));
         }
     } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over the tile's 256 columns
         // Each wave reduces its 64 columns, the 4 column strips of a row meet in LDS (the operand
