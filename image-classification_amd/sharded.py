@@ -73,7 +73,7 @@ class ShardedKnn:
     """
 
     def __init__(self, bank_rows_local: torch.Tensor, idx_base: int, group=None, ops=None,
-                 compute_dtype=None, query_chunk: int = 8192, n_streams: int = 1):
+                 compute_dtype=None, query_chunk: int = 8192, n_streams: int = 1, always_exchange: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if _dist_on() else 1
         self.rank = dist.get_rank(group) if _dist_on() else 0
@@ -83,8 +83,11 @@ class ShardedKnn:
         self.n_local = int(self.ops.bank_rows(self.bank))
         self.query_chunk = int(query_chunk)
         self.n_streams = max(1, int(n_streams))
+        # always_exchange: a one-rank group still goes through the collectives and the merge (lets a one-GPU box
+        # run the RCCL branches); otherwise a single rank skips them
+        self.solo = self.world == 1 and not (always_exchange and _dist_on())
         sizes = [self.n_local]
-        if self.world > 1:
+        if not self.solo:
             t = torch.tensor([self.n_local], dtype=torch.int64, device=bank_rows_local.device)
             out = [torch.empty_like(t) for _ in range(self.world)]
             dist.all_gather(out, t, group=group)
@@ -95,7 +98,7 @@ class ShardedKnn:
     # -- one exchange step ------------------------------------------------------------------
     def _exchange(self, val: torch.Tensor, idx: torch.Tensor):
         """all-gather [B, k] candidates -> [G, B, k]; returns (gathered_val, gathered_idx, works)."""
-        if self.world == 1:
+        if self.solo:
             return val[None], idx[None], ()
         G = self.world
         gv = torch.empty((G,) + tuple(val.shape), dtype=val.dtype, device=val.device)
@@ -166,7 +169,7 @@ class ShardedKnn:
         gv, gi, works = pending
         for w in works:
             w.wait()
-        if self.world == 1:
+        if self.solo:
             return gv[0], gi[0]
         return self.ops.merge(gv, gi, k)
 
@@ -180,7 +183,7 @@ class ShardedKnn:
         G, c, k = self.world, val.shape[0], val.shape[1]
         lo, hi = shard_bounds(c, G, self.rank)
         send = torch.stack((val.contiguous().view(torch.int32), idx.to(torch.int32)), dim=1)        # [c, 2, k]
-        if G == 1:
+        if self.solo:
             return send[None], None
         if dist.get_backend(self.group) == "nccl":
             sizes = [shard_bounds(c, G, j)[1] - shard_bounds(c, G, j)[0] for j in range(G)]
@@ -202,7 +205,7 @@ class ShardedKnn:
             return torch.empty((0, classes), dtype=torch.int64, device=buf.device)
         val = buf[:, :, 0, :].contiguous().view(torch.float32)
         idx = buf[:, :, 1, :].to(torch.int64)
-        if self.world > 1:
+        if not self.solo:
             val, idx = self.ops.merge(val, idx, k)
         else:
             val, idx = val[0], idx[0]
@@ -243,7 +246,7 @@ class ShardedKnn:
         slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
         self.local_rows = torch.cat(rows)
         self.local_ranking = torch.cat(slices, 0)
-        if G == 1:
+        if self.solo:
             return self.local_ranking if gather == "full" else self.local_ranking[:, 0].contiguous()
         # final gather: pad every rank's slice to the same length, then undo the (chunk, owner) interleave
         mine = self.local_ranking if gather == "full" else self.local_ranking[:, :1]

@@ -254,3 +254,31 @@ def test_pack_rows(ica):
         assert torch.equal(p.data.cpu(), ref) and torch.equal(pt.data.cpu(), ref)
     y = dev(rs.randn(8, 64).astype(np.float32))
     assert ica.pack_rows(y, False, "fp32").data.data_ptr() == y.data_ptr()           # zero copy
+
+
+def test_rccl_branches_on_one_rank_group(ica):
+    """The RCCL (backend "nccl") branches of ShardedKnn -- all_to_all_single of the packed candidates,
+    all_gather_into_tensor of the rankings / top-k -- run on a one-rank group on this one-GPU box and must
+    reproduce the unsharded result bit for bit (more ranks: the gloo tests of the same orchestration)."""
+    import os
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        f, x, lab = _rand_case(700, 9000, 64, 10, 5)
+        k = 200
+        bank = ica.BankIndex.from_rows(dev(x), "bf16")
+        ref = ica.knn_predict(dev(f), bank, dev(lab), 10, k, 0.1)
+        v_ref, i_ref = ica.knn_topk(dev(f), bank, k)
+        knn = ica.sharded.ShardedKnn(dev(x), 0, compute_dtype="bf16", query_chunk=256, always_exchange=True)
+        assert not knn.solo and knn.shard_sizes == [9000]
+        assert torch.equal(knn.predict(dev(f), dev(lab), 10, k, 0.1), ref)
+        assert torch.equal(knn.predict(dev(f), dev(lab), 10, k, 0.1, gather="top1"), ref[:, 0])
+        assert torch.equal(knn.local_ranking, ref) and torch.equal(knn.local_rows.cpu(), torch.arange(700))
+        v, i = knn.topk(dev(f), k)
+        assert torch.equal(v, v_ref) and torch.equal(i, i_ref)
+    finally:
+        dist.destroy_process_group()
