@@ -232,18 +232,37 @@ class ShardedKnn:
             raise ValueError("the candidate exchange carries int32 global rows: N must be < 2^31")
         B, G = feature.shape[0], self.world
         starts = list(range(0, B, self.query_chunk))
-        slices, rows = [], []
-        pending = None
-        for s in starts:
+        slices, rows = [None] * len(starts), []
+        # n_streams > 1: query chunks alternate between side streams, so the threshold refreshes, launch gaps,
+        # exchange, merge and vote of one chunk run beside the other chunk's GEMM (pays when the shard is small)
+        side = _side_streams(feature.device, self.n_streams) if (feature.is_cuda and self.n_streams > 1
+                                                                  and len(starts) > 1) else None
+        main = torch.cuda.current_stream(feature.device) if side else None
+
+        def on_stream(i):
+            return torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()
+
+        pending = None                                   # (chunk number, exchange in flight)
+        for i, s in enumerate(starts):
+            if side and i < len(side):
+                side[i].wait_stream(main)                # inputs were produced on the caller's stream
             f = feature[s:s + self.query_chunk]
-            val, idx = self._local_candidates(f, k)
-            nxt = self._to_owners(val, idx)              # chunk s's exchange runs beside the next chunk's GEMM
+            with on_stream(i):
+                val, idx = self._local_candidates(f, k)
+                nxt = self._to_owners(val, idx)          # chunk i's exchange runs beside the next chunk's GEMM
             if pending is not None:
-                slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
-            pending = nxt
+                with on_stream(pending[0]):
+                    slices[pending[0]] = self._own_slice(pending[1], k, feature_labels, classes, knn_t)
+            pending = (i, nxt)
             lo, hi = shard_bounds(f.shape[0], G, self.rank)
             rows.append(torch.arange(s + lo, s + hi, device=feature.device))
-        slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
+        with on_stream(pending[0]):
+            slices[pending[0]] = self._own_slice(pending[1], k, feature_labels, classes, knn_t)
+        if side:
+            for st in side[:len(starts)]:
+                main.wait_stream(st)
+            for sl in slices:
+                sl.record_stream(main)
         self.local_rows = torch.cat(rows)
         self.local_ranking = torch.cat(slices, 0)
         if self.solo:
