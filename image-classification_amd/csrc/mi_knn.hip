@@ -562,7 +562,8 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
     {
         ProfScope ps(MI_PROF_SELECT, (double)B * sel.dense_n * 4.0, s);
-        hipLaunchKernelGGL((mi::select_kernel<mi::SRC_DENSE>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
+        if (k <= mi::WSEL_MAX_K) hipLaunchKernelGGL((mi::wave_select_kernel<mi::SRC_DENSE>), dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, sel);
+        else hipLaunchKernelGGL((mi::select_kernel<mi::SRC_DENSE>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
         HIP_CHECK(hipGetLastError());
     }
 
@@ -592,7 +593,8 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
             else if (k <= 512) hipLaunchKernelGGL((mi::merge_kernel<8>), mgrid, dim3(256), 0, s, sel);
             else hipLaunchKernelGGL((mi::merge_kernel<16>), mgrid, dim3(256), 0, s, sel);
             HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3(2048), dim3(mi::SEL_THREADS), 0, s, sel);
+            if (k <= mi::WSEL_MAX_K) hipLaunchKernelGGL((mi::wave_select_kernel<mi::SRC_LIST>), dim3(1024), dim3(256), 0, s, sel);
+            else hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3(2048), dim3(mi::SEL_THREADS), 0, s, sel);
             HIP_CHECK(hipGetLastError());
         }
     }

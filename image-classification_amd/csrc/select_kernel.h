@@ -337,6 +337,218 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const SelectParams 
     select_row<SRC>(p, blockIdx.x, sm);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-per-row select (k <= 256): the workgroup-per-row kernel above spends its time in barriers
+// (~60 per row) with three of its four waves idle in the scans; here ONE wave owns a row, its keys
+// sit in a wave-private LDS block, and nothing waits for another wave.  LDS operations of one wave
+// complete in order, so only the compiler has to be kept from moving accesses across the steps.
+constexpr int WSEL_CAP = 1024;               // keys of one row in LDS: the kept <= 256 + one batch of candidates
+constexpr int WSEL_MAX_K = 256;
+
+struct WaveSmem {
+    unsigned long long keys[WSEL_CAP];
+    unsigned hist[256];
+};
+
+__device__ __forceinline__ void wave_step() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// rank-th largest (1-based) of the non-zero keys in sm.keys[0, tot): as radix_select_kth, by one wave.
+__device__ __forceinline__ unsigned long long wave_radix_select_kth(WaveSmem &sm, int tot, int rank, int lane)
+{
+    unsigned long long a = ~0ull, o = 0ull;
+    for (int i = lane; i < tot; i += 64) {
+        const unsigned long long key = sm.keys[i];
+        if (key) { a &= key; o |= key; }
+    }
+    a = wave_and64(a);
+    o = wave_or64(o);
+    const unsigned long long var = a ^ o;
+    if (var == 0ull) return a;                                   // a single distinct key
+    const int hb = 63 - __clzll((long long)var);
+    unsigned long long pmask = hb == 63 ? 0ull : ~((2ull << hb) - 1ull);
+    unsigned long long prefix = a & pmask;
+    unsigned r = (unsigned)rank;
+    for (int top = hb; top >= 0; top -= 8) {
+        const int sh = top >= 7 ? top - 7 : 0;
+        const unsigned dmask = top >= 7 ? 255u : ((1u << (top + 1)) - 1u);
+        *(uint4 *)&sm.hist[4 * lane] = make_uint4(0u, 0u, 0u, 0u);
+        wave_step();
+        for (int i = lane; i < tot; i += 64) {
+            const unsigned long long key = sm.keys[i];
+            if (key && (key & pmask) == prefix) atomicAdd(&sm.hist[(unsigned)(key >> sh) & dmask], 1u);
+        }
+        wave_step();
+        const uint4 h = *(const uint4 *)&sm.hist[4 * lane];      // lane l owns bins 4l .. 4l+3
+        const unsigned mine = h.x + h.y + h.z + h.w;
+        unsigned incl = mine;                                    // sum over lanes >= this one
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_down(incl, d, 64);
+            if (lane + d < 64) incl += t;
+        }
+        const unsigned above = incl - mine;
+        const bool hit = above < r && r <= incl;                 // exactly one lane
+        unsigned acc = above, hcnt = h.w;
+        int b = 4 * lane + 3;
+        if (acc + h.w < r) { acc += h.w; b = 4 * lane + 2; hcnt = h.z;
+            if (acc + h.z < r) { acc += h.z; b = 4 * lane + 1; hcnt = h.y;
+                if (acc + h.y < r) { acc += h.y; b = 4 * lane; hcnt = h.x; } } }
+        const int src = __ffsll((long long)__ballot(hit)) - 1;
+        const unsigned bin = (unsigned)__shfl(b, src, 64);
+        const unsigned bin_count = __shfl(hcnt, src, 64);
+        r = __shfl(r - acc, src, 64);
+        prefix |= (unsigned long long)bin << sh;
+        pmask |= (unsigned long long)dmask << sh;
+        if (sh == 0) break;
+        if (bin_count == 1u) {                                   // one key left under this prefix: it is the answer
+            unsigned long long found = 0ull;
+            for (int i = lane; i < tot; i += 64) {
+                const unsigned long long key = sm.keys[i];
+                if (key && (key & pmask) == prefix) found = key;
+            }
+            return wave_or64(found);
+        }
+        wave_step();
+    }
+    return prefix;
+}
+
+// Descending bitonic sort of n (power of two, 64 <= n <= WSEL_CAP) keys in a wave-private LDS block.
+__device__ __forceinline__ void wave_bitonic_sort_desc(unsigned long long *keys, int n, int lane)
+{
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (n >> 1); t += 64) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+            wave_step();
+        }
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ void wave_select_row(const SelectParams &p, const long long row, WaveSmem &sm, const int lane)
+{
+    static_assert(SRC == SRC_LIST || SRC == SRC_DENSE, "wave select: candidate lists or dense rows");
+    unsigned long long *keys = sm.keys;
+    const int n_new = SRC == SRC_LIST ? p.ntiles : p.dense_n;      // SRC_LIST: tiles to consume (counts are per tile)
+    const bool finalize = p.out_val != nullptr;
+    if (n_new == 0 && !finalize) return;
+    int n_cur = p.topk_n[row];
+    for (int i = lane; i < n_cur; i += 64) keys[i] = p.topk[row * p.k + i];
+    bool touched = false;
+    int pos = 0;
+    while (pos < n_new) {
+        const int room = WSEL_CAP - n_cur;
+        int m, step, nz = 0;
+        if constexpr (SRC == SRC_LIST) {
+            // the longest run of tiles from `pos` (one per lane) whose candidates fit the room (a tile holds
+            // <= 256, room >= 768: progress)
+            const int t = pos + lane;
+            int c = 0;
+            if (t < n_new && ((p.tmask[row * p.mask_words + (t >> 5)] >> (t & 31)) & 1u))
+                c = (int)p.cnt2[(long long)t * p.bpad + row];
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            const bool fits = t < n_new && incl <= room;
+            step = __popcll(__ballot(fits));                       // a prefix of the lanes: incl is monotone
+            m = __shfl(incl, step - 1, 64);
+            if (fits) {
+                const uint2 *seg = p.cand + row * p.cap + (long long)t * 256;
+                for (int e = 0; e < c; ++e) {
+                    const uint2 cd = seg[e];
+                    const unsigned long long key = make_key(__uint_as_float(cd.x), cd.y);
+                    keys[n_cur + incl - c + e] = key;
+                    nz += key != 0ull;
+                }
+            }
+        } else {
+            m = (n_new - pos) < room ? (n_new - pos) : room;
+            step = m;
+            const float *d = (const float *)p.cand + row * 2 * p.cap;
+            for (int i = lane; i < m; i += 64) {
+                const unsigned long long key = make_key(d[pos + i], (unsigned)(p.dense_col0 + pos + i));
+                keys[n_cur + i] = key;
+                nz += key != 0ull;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d, 64);
+        wave_step();
+        const int tot = n_cur + m;
+        nz += n_cur;                                               // the kept keys of earlier batches are all real
+        const int keep = nz < p.k ? nz : p.k;
+        unsigned long long kth = 1ull;                             // nz <= k: keep every real key
+        if (nz > keep) kth = wave_radix_select_kth(sm, tot, keep, lane);
+        wave_step();
+        // ordered in-place compaction of the `keep` keys >= kth (they are distinct): a chunk is read before it
+        // is written, and writes never reach a chunk not yet read
+        int base = 0;
+        for (int c0 = 0; c0 < tot; c0 += 64) {
+            const int i = c0 + lane;
+            const unsigned long long key = i < tot ? keys[i] : 0ull;
+            const bool take = key >= kth;
+            const unsigned long long bal = __ballot(take);
+            wave_step();
+            if (take) keys[base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+            base += __popcll(bal);
+        }
+        wave_step();
+        n_cur = keep;
+        pos += step;
+        touched = true;
+    }
+    if (touched) {
+        int n2 = 64;
+        while (n2 < n_cur) n2 <<= 1;
+        for (int i = n_cur + lane; i < n2; i += 64) keys[i] = 0ull;
+        wave_step();
+        wave_bitonic_sort_desc(keys, n2, lane);
+    }
+    if constexpr (SRC == SRC_LIST) {
+        for (int i = lane; i < p.mask_words; i += 64) p.tmask[row * p.mask_words + i] = 0u;
+    }
+    for (int i = lane; i < n_cur; i += 64) p.topk[row * p.k + i] = keys[i];
+    if (lane == 0) {
+        p.topk_n[row] = n_cur;
+        p.tau[row] = (n_cur >= p.k) ? key_value(keys[p.k - 1]) : -INFINITY;
+    }
+    if (finalize) {
+        for (int i = lane; i < p.k; i += 64) {
+            const bool ok = i < n_cur;
+            p.out_val[row * p.k + i] = ok ? key_value(keys[i]) : -INFINITY;
+            p.out_idx[row * p.k + i] = ok ? p.idx_base + (long long)key_row(keys[i]) : -1ll;
+        }
+    }
+    wave_step();                                                   // the LDS block is reused by this wave's next row
+}
+
+// SRC_DENSE: wave w of the grid serves query row w.  SRC_LIST: the rows merge_kernel left in the 64 work lists;
+// wave w serves list w % 64, every (waves / 64)-th entry.
+template <int SRC>
+__global__ __launch_bounds__(256) void wave_select_kernel(const SelectParams p)
+{
+    __shared__ WaveSmem sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned gw = blockIdx.x * 4 + w;
+    if constexpr (SRC == SRC_LIST) {
+        const unsigned sub = gw & (BIG_SUBLISTS - 1), per = gridDim.x * 4 / BIG_SUBLISTS;
+        const unsigned n = p.big_cnt[(p.parity * BIG_SUBLISTS + sub) * 32];
+        for (unsigned i = gw / BIG_SUBLISTS; i < n; i += per)
+            wave_select_row<SRC>(p, (long long)p.big_rows[(long long)sub * p.big_stride + i], sm[w], lane);
+    } else {
+        if ((long long)gw < p.B) wave_select_row<SRC>(p, (long long)gw, sm[w], lane);
+    }
+}
+
 // Wave-per-row merge: the common case after the first few stages is a handful of new candidates
 // per row.  One wave holds the row's sorted top-k in registers (KPL keys per lane, key i on lane
 // i % 64) and its <= 64 new candidates one per lane, and computes every key's position in the
