@@ -439,7 +439,15 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
     const bool finalize = p.out_val != nullptr;
     if (n_new == 0 && !finalize) return;
     int n_cur = p.topk_n[row];
-    for (int i = lane; i < n_cur; i += 64) keys[i] = p.topk[row * p.k + i];
+    {
+        // every global load of a batch is issued before the first LDS store waits for one (k <= 256: 4 per lane)
+        unsigned long long pk[WSEL_MAX_K / 64];
+#pragma unroll
+        for (int j = 0; j < WSEL_MAX_K / 64; ++j) pk[j] = (j * 64 + lane) < n_cur ? p.topk[row * p.k + j * 64 + lane] : 0ull;
+#pragma unroll
+        for (int j = 0; j < WSEL_MAX_K / 64; ++j)
+            if ((j * 64 + lane) < n_cur) keys[j * 64 + lane] = pk[j];
+    }
     bool touched = false;
     int pos = 0;
     while (pos < n_new) {
@@ -461,23 +469,56 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
             const bool fits = t < n_new && incl <= room;
             step = __popcll(__ballot(fits));                       // a prefix of the lanes: incl is monotone
             m = __shfl(incl, step - 1, 64);
-            if (fits) {
-                const uint2 *seg = p.cand + row * p.cap + (long long)t * 256;
-                for (int e = 0; e < c; ++e) {
-                    const uint2 cd = seg[e];
-                    const unsigned long long key = make_key(__uint_as_float(cd.x), cd.y);
-                    keys[n_cur + incl - c + e] = key;
-                    nz += key != 0ull;
+            if (fits && c) {
+                // 8 candidates (4 x 16 bytes) in flight per lane; slot c of an odd count is read (inside the
+                // segment) and ignored
+                const uint4 *seg = (const uint4 *)(p.cand + row * p.cap + (long long)t * 256);
+                unsigned long long *dst = keys + n_cur + incl - c;
+                for (int e0 = 0; e0 < c; e0 += 8) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (e0 + 2 * j < c) v[j] = seg[(e0 >> 1) + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = e0 + 2 * j;
+                        if (e < c) {
+                            const unsigned long long key = make_key(__uint_as_float(v[j].x), v[j].y);
+                            dst[e] = key;
+                            nz += key != 0ull;
+                        }
+                        if (e + 1 < c) {
+                            const unsigned long long key = make_key(__uint_as_float(v[j].z), v[j].w);
+                            dst[e + 1] = key;
+                            nz += key != 0ull;
+                        }
+                    }
                 }
             }
         } else {
-            m = (n_new - pos) < room ? (n_new - pos) : room;
+            m = (n_new - pos) < room ? (n_new - pos) : (room & ~3);     // pos stays a multiple of 4: 16-byte loads
             step = m;
-            const float *d = (const float *)p.cand + row * 2 * p.cap;
-            for (int i = lane; i < m; i += 64) {
-                const unsigned long long key = make_key(d[pos + i], (unsigned)(p.dense_col0 + pos + i));
-                keys[n_cur + i] = key;
-                nz += key != 0ull;
+            const float *d = (const float *)p.cand + row * 2 * p.cap + pos;
+            for (int i0 = 0; i0 < m; i0 += 1024) {                       // 4 x 16 bytes in flight per lane
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 4 * (j * 64 + lane);
+                    if (i < m) v[j] = *(const float4 *)(d + i);          // the row is padded to a multiple of 1024 floats
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 4 * (j * 64 + lane);
+                    const float f[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (i + u < m) {
+                            const unsigned long long key = make_key(f[u], (unsigned)(p.dense_col0 + pos + i + u));
+                            keys[n_cur + i + u] = key;
+                            nz += key != 0ull;
+                        }
+                    }
+                }
             }
         }
 #pragma unroll
