@@ -285,6 +285,7 @@ struct Plan {
     int s0_cols;        // dense bootstrap stage
     int min_cols;       // smallest useful filter stage (enough workgroups to fill the chip)
     int cap;            // candidate slots per row (>= every stage's columns: overflow impossible)
+    int launch_cols;    // columns of one GEMM launch (<= cap): a stage is one or more launches, then ONE refresh
     size_t off_tau, off_topkn, off_big, off_topk, off_mask, off_cnt2, off_cand, fixed, total;
     int mask_words;
 };
@@ -297,7 +298,10 @@ constexpr int BIG_CNT_BYTES = 2 * mi::BIG_SUBLISTS * 128;      // one 128-byte l
 // rows (row >> 2) % 64 == s go to sub-list s: at most 4 * ceil(B_pad / 256) of them
 inline int big_stride(int B_pad) { return 4 * (int)ceil_div(B_pad, 4 * mi::BIG_SUBLISTS); }
 constexpr int STAGE_QUANTUM = 1024;                // filter stages are whole multiples of 4 bank tiles
-constexpr int64_t CAND_BUDGET_BYTES = 8ll << 30;   // default size of the candidate buffer
+#ifndef MI_CAND_BUDGET_GIB
+#define MI_CAND_BUDGET_GIB 8
+#endif
+constexpr int64_t CAND_BUDGET_BYTES = (int64_t)MI_CAND_BUDGET_GIB << 30;   // default size of the candidate buffer
 
 // Workspace layout.  cand_bytes < 0: the default candidate budget; otherwise what the caller gave.
 Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row_bytes = 0)
@@ -317,13 +321,16 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     // Keep one stage's bank slice (+ the query chunk) resident in the 256 MiB Infinity Cache: the
     // slice is re-read once per group of 8 query tiles, and the K loop is latency sensitive (a
     // 268 MB slice ran 12 % slower than a 134 MB one at C4).
+    int64_t launch = cap;
     if (bank_row_bytes > 0) {
         int64_t fit = ((128ll << 20) / bank_row_bytes) / STAGE_QUANTUM * STAGE_QUANTUM;
         if (fit < 8 * STAGE_QUANTUM) fit = 8 * STAGE_QUANTUM;
-        if (cap > fit) cap = fit;
+        if (launch > fit) launch = fit;
     }
     if (cap < S0_COLS) cap = cand_bytes < 0 ? S0_COLS : 0;      // 0: the caller's workspace is too small
+    if (launch < S0_COLS) launch = cap;
     pl.cap = (int)cap;
+    pl.launch_cols = (int)launch;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (size_t)round_up((int64_t)(off + bytes), 256); return o; };
     pl.off_tau = take((size_t)pl.B_pad * 4);
@@ -339,16 +346,25 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     return pl;
 }
 
-// Filter stage schedule.  A stage filters with the threshold tau known at its start (the k-th best
-// of the `seen` columns before it), so about k * ln(1 + n / seen) elements per row pass it: stages
-// grow geometrically (n = seen) -- ~k ln 2 survivors per row and stage, O(log N) threshold
-// refreshes -- until the candidate buffer (worst case: every element passes) or the cache-fit
-// limit caps them.  Growth factor 4 (n = 3 * seen): small launches run well below the large ones'
-// rate, so the ramp is kept short at the price of ~3k instead of ~k candidates in its stages.
+// Filter stage schedule.  A stage filters with the threshold tau known at its start (the k-th best of the
+// `seen` columns before it), so about k * ln(1 + n / seen) elements per row pass a stage of n columns -- the
+// total over a run does not depend on how it is cut into stages, the number of threshold refreshes does.
+//   ramp: n = 3 * seen (growth factor 4: small launches run well below the large ones' rate, so the ramp is kept
+//         short at the price of ~3k instead of ~k candidates in its stages), up to one cache-fit launch;
+//   then: n = seen / 4, at least one launch: ~k ln 1.25 = 0.22 k candidates per row and stage (within the
+//         wave-per-row merge's 64) and O(log N) refreshes instead of one per launch;
+//   always <= cap: the candidate buffer holds the worst case of one stage (every element passes).
+#ifndef MI_LATE_GROWTH_DIV
+#define MI_LATE_GROWTH_DIV 4
+#endif
 int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t N)
 {
     int64_t n = 3 * seen / STAGE_QUANTUM * STAGE_QUANTUM;
     if (n < pl.min_cols) n = pl.min_cols;
+    if (n > pl.launch_cols) {
+        n = seen / MI_LATE_GROWTH_DIV / pl.launch_cols * pl.launch_cols;      // whole launches
+        if (n < pl.launch_cols) n = pl.launch_cols;
+    }
     if (n > pl.cap) n = pl.cap;
     if (n > N - seen) n = N - seen;
     return n;
@@ -574,12 +590,14 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
     for (int stage = 0; col < N; ++stage) {
         sel.parity = stage & 1;
         const int64_t ncols = next_stage_cols(pl, col, N);
-        sp.col0 = (int)col;
-        sp.ncols = (int)ncols;
-        sp.ntiles = (int)ceil_div(ncols, mi::TILE);
-        sel.ntiles = sp.ntiles;
-        {
-            ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)ncols * (double)D, s);
+        sel.ntiles = (int)ceil_div(ncols, mi::TILE);
+        for (int64_t off = 0; off < ncols; off += pl.launch_cols) {          // launch_cols is a whole number of tiles
+            const int64_t lc = ncols - off < pl.launch_cols ? ncols - off : pl.launch_cols;
+            sp.col0 = (int)(col + off);
+            sp.ncols = (int)lc;
+            sp.ntiles = (int)ceil_div(lc, mi::TILE);
+            sp.nt_base = (int)(off / mi::TILE);
+            ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)lc * (double)D, s);
             HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
         }
         col += ncols;

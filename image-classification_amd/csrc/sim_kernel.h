@@ -50,7 +50,8 @@ struct SimParams {
     long long ldq_bytes, ldx_bytes;
     int B, N;                 // valid rows of q / x
     int ksteps;               // padded row bytes / 128
-    int col0, ncols;          // this stage covers bank rows [col0, col0 + ncols)
+    int col0, ncols;          // this launch covers bank rows [col0, col0 + ncols)
+    int nt_base;              // MODE_FILTER: stage tile of the launch's tile 0 (a stage may take several launches)
     int qtiles, ntiles;       // tiles in this launch
     int pq, pn, qsh;          // patches of (1 << qsh) query tiles x (32 >> qsh) bank tiles (set by the launcher)
     // MODE_DENSE / MODE_FILTER
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 if (__any(m >= t)) {
                     const int rl = wm * 128 + lq * 4 + i * 16 + r;        // row within the tile
                     if (q0 + rl < p.B) {
-                        uint2 *seg = p.cand + (long long)(q0 + rl) * p.cap + (long long)nt * TILE;
+                        uint2 *seg = p.cand + (long long)(q0 + rl) * p.cap + (long long)(p.nt_base + nt) * TILE;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float v = acc[i][j][r];
@@ -411,9 +412,10 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         __syncthreads();
         if (tid < TILE) {
             const unsigned n = lcnt[tid];
-            p.cnt2[(long long)nt * p.bpad + q0 + tid] = (unsigned short)n;           // one contiguous block per tile
+            const int st = p.nt_base + nt;                                           // tile of the stage
+            p.cnt2[(long long)st * p.bpad + q0 + tid] = (unsigned short)n;           // one contiguous block per tile
             // which tiles to look at, per row: a no-return atomic (nothing waits for it)
-            if (n) atomicOr(p.tmask + (long long)(q0 + tid) * p.mask_words + (nt >> 5), 1u << (nt & 31));
+            if (n) atomicOr(p.tmask + (long long)(q0 + tid) * p.mask_words + (st >> 5), 1u << (st & 31));
         }
     } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over the tile's 256 columns
         // Each wave reduces its 64 columns, the 4 column strips of a row meet in LDS (the operand
