@@ -298,6 +298,9 @@ constexpr int BIG_CNT_BYTES = 2 * mi::BIG_SUBLISTS * 128;      // one 128-byte l
 // rows (row >> 2) % 64 == s go to sub-list s: at most 4 * ceil(B_pad / 256) of them
 inline int big_stride(int B_pad) { return 4 * (int)ceil_div(B_pad, 4 * mi::BIG_SUBLISTS); }
 constexpr int STAGE_QUANTUM = 1024;                // filter stages are whole multiples of 4 bank tiles
+#ifndef MI_FIT_MB
+#define MI_FIT_MB 128
+#endif
 #ifndef MI_CAND_BUDGET_GIB
 #define MI_CAND_BUDGET_GIB 8
 #endif
@@ -323,7 +326,7 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     // 268 MB slice ran 12 % slower than a 134 MB one at C4).
     int64_t launch = cap;
     if (bank_row_bytes > 0) {
-        int64_t fit = ((128ll << 20) / bank_row_bytes) / STAGE_QUANTUM * STAGE_QUANTUM;
+        int64_t fit = (((int64_t)MI_FIT_MB << 20) / bank_row_bytes) / STAGE_QUANTUM * STAGE_QUANTUM;
         if (fit < 8 * STAGE_QUANTUM) fit = 8 * STAGE_QUANTUM;
         if (launch > fit) launch = fit;
     }

@@ -95,6 +95,15 @@ __device__ __forceinline__ float row16_sum(float v)
 #ifndef MI_DMA_SHIFT
 #define MI_DMA_SHIFT 0
 #endif
+#ifndef MI_L2_PREFETCH
+#define MI_L2_PREFETCH 1
+#endif
+#ifndef MI_PF_DIST
+#define MI_PF_DIST 2
+#endif
+#ifndef MI_PF_ALL
+#define MI_PF_ALL 0
+#endif
 
 template <int DT, int MODE>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
@@ -183,9 +192,50 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             : "memory");
     };
 #if defined(MI_ABLATE) && (MI_ABLATE & 16)
-    auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); };   // timing-only: one K-step of DMA stays in flight
+    auto stage_wait = [&](auto) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); };   // timing-only: one K-step of DMA stays in flight
 #else
-    auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // vmcnt counts in issue order: with a prefetch issued after the K-step's DMA, vmcnt(1) waits for the DMA only
+    auto stage_wait = [&](auto pf_tag) {
+        if constexpr (decltype(pf_tag)::value) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#endif
+
+#if MI_L2_PREFETCH
+    // ---- L2 prefetch.  The 32 workgroups of an XCD patch stream the same 8 + 4 operand tiles, so 19 % of the
+    // DMA requests -- the first touch of every line in this XCD -- miss the L2 and take the Infinity-Cache
+    // latency, which a two-buffer pipeline cannot hide (one K-step of lead).  Each workgroup therefore touches
+    // its share of the lines of the K-step AFTER next (A tile: 4 sharers x 64 rows, B tile: 8 sharers x 32 rows
+    // = 96 lines, 12 per wave) with a plain dword load into a register nobody reads: the DMA one step later hits.
+    const char *pf_src;
+    {
+#if MI_PF_ALL
+        const int idx = w * 64 + lane;                      // experiment: every workgroup touches all its own lines
+        if (idx < 256) {
+            int r = q0 + idx; r = r < p.B ? r : p.B - 1;
+            pf_src = p.q + (long long)r * p.ldq_bytes;
+        } else {
+            int r = n0 + idx - 256; r = r < p.N ? r : p.N - 1;
+            pf_src = p.x + (long long)r * p.ldx_bytes;
+        }
+#else
+        const int idx = w * 12 + (lane % 12);
+        if (idx < 64) {
+            int r = q0 + 64 * ((inner >> 3) & 3) + idx; r = r < p.B ? r : p.B - 1;
+            pf_src = p.q + (long long)r * p.ldq_bytes;
+        } else {
+            int r = n0 + 32 * (inner & 7) + (idx - 64); r = r < p.N ? r : p.N - 1;
+            pf_src = p.x + (long long)r * p.ldx_bytes;
+        }
+#endif
+    }
+    unsigned pf_sink = 0u;                                  // stays live across the K loop: the register is reserved
+    auto prefetch = [&](int t) {
+        t = t < p.ksteps ? t : p.ksteps - 1;                // never past the end of a row
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_src + (long long)t * KSTEP_BYTES) : "memory");
+    };
+#else
+    auto prefetch = [&](int) {};
 #endif
 
     // ---- MFMA operand read offsets.  Lane reads row (lane & 15) of a 16-row block; K chunk
@@ -216,8 +266,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     // (the reads of group g+1 are issued before the MFMAs of group g, two register sets) and the
     // next K-step's DMA is spread over the first four groups (one A + one B piece each) instead of
     // being issued as a burst: a burst keeps BOTH waves of a SIMD out of the matrix pipe at once.
-    auto kstep = [&](int t, auto dma_tag) {
+    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {
         constexpr bool DMA = decltype(dma_tag)::value;
+        constexpr bool PF = decltype(pf_tag)::value;
         const char *lds = smem + (t & 1) * STAGE_BYTES;
         const int nbuf = (t + 1) & 1;
         if constexpr (DT == DT_BF16) {
@@ -241,6 +292,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     if (pr < 4) { if (w < 4) stage_pair(pr, t + 1, nbuf); }
                     if (pr >= MI_DMA_SHIFT && pr < MI_DMA_SHIFT + 4) { if (w >= 4) stage_pair(pr - MI_DMA_SHIFT, t + 1, nbuf); }
 #endif
+                }
+                if constexpr (PF) {
+                    if (pr == 4) prefetch(t + MI_PF_DIST);
                 }
                 if (pr < 7) {
                     const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;
@@ -298,6 +352,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 if constexpr (DMA) {
                     if (kk < 4) stage_pair(kk, t + 1, nbuf);
                 }
+                if constexpr (PF) {
+                    if (kk == 4) prefetch(t + MI_PF_DIST);
+                }
                 if (kk < 7) {
                     const int co = (((kk + 1) ^ sw) * 16) + lq * 4;
 #pragma unroll
@@ -321,7 +378,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             MI_RD(12); MI_MM(32);
             MI_MM(32);
         }
-        stage_wait();
+        stage_wait(pf_tag);
         __syncthreads();
     };
 #undef MI_RD
@@ -329,13 +386,19 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_pair(i, 0, 0);
-    stage_wait();
+    stage_wait(std::false_type{});
     __syncthreads();
 #if defined(MI_ABLATE) && (MI_ABLATE & 2)
-    for (int t = 0; t < p.ksteps; ++t) kstep(t, std::false_type{});          // timing-only: no DMA in the loop
+    for (int t = 0; t < p.ksteps; ++t) kstep(t, std::false_type{}, std::false_type{});          // timing-only: no DMA in the loop
+#elif MI_L2_PREFETCH
+    for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{});
+    if (p.ksteps > 1) kstep(p.ksteps - 2, std::true_type{}, std::false_type{});
+    kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pf_sink));
 #else
-    for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{});
-    kstep(p.ksteps - 1, std::false_type{});
+    for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{}, std::false_type{});
+    kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
 #endif
 
     // ---- epilogue.  C/D map of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg.
