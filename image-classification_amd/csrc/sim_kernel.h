@@ -104,6 +104,12 @@ __device__ __forceinline__ float row16_sum(float v)
 #ifndef MI_PF_ALL
 #define MI_PF_ALL 0
 #endif
+#ifndef MI_PF_RED2
+#define MI_PF_RED2 0
+#endif
+#ifndef MI_PF_POS
+#define MI_PF_POS 4
+#endif
 
 template <int DT, int MODE>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
@@ -218,6 +224,15 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             int r = n0 + idx - 256; r = r < p.N ? r : p.N - 1;
             pf_src = p.x + (long long)r * p.ldx_bytes;
         }
+#elif MI_PF_RED2
+        const int idx = w * 24 + (lane % 24);               // experiment: every line touched by two of its sharers
+        if (idx < 128) {
+            int r = q0 + 128 * ((inner >> 3) & 1) + idx; r = r < p.B ? r : p.B - 1;
+            pf_src = p.q + (long long)r * p.ldq_bytes;
+        } else {
+            int r = n0 + 64 * (inner & 3) + (idx - 128); r = r < p.N ? r : p.N - 1;
+            pf_src = p.x + (long long)r * p.ldx_bytes;
+        }
 #else
         const int idx = w * 12 + (lane % 12);
         if (idx < 64) {
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #endif
                 }
                 if constexpr (PF) {
-                    if (pr == 4) prefetch(t + MI_PF_DIST);
+                    if (pr == MI_PF_POS) prefetch(t + MI_PF_DIST);
                 }
                 if (pr < 7) {
                     const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;
