@@ -394,7 +394,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             MI_MM(32);
         }
         stage_wait(pf_tag);
-        __syncthreads();
+#if !(defined(MI_ABLATE) && (MI_ABLATE & 512))
+        __syncthreads();                                            // (ablation 512, timing only: no K-step barrier)
+#endif
     };
 #undef MI_RD
 #undef MI_MM
