@@ -181,10 +181,10 @@ class ShardedKnn:
         instead of c x G x k.  Payload: (float32 score bits, int32 global row) in one int32 tensor.
         Returns (buffer [G, c_j, 2, k] int32, pending work or None)."""
         G, c, k = self.world, val.shape[0], val.shape[1]
+        if self.solo:
+            return (val, idx), None                      # one rank, no exchange: the candidates are the result
         lo, hi = shard_bounds(c, G, self.rank)
         send = torch.stack((val.contiguous().view(torch.int32), idx.to(torch.int32)), dim=1)        # [c, 2, k]
-        if self.solo:
-            return send[None], None
         if dist.get_backend(self.group) == "nccl":
             sizes = [shard_bounds(c, G, j)[1] - shard_bounds(c, G, j)[0] for j in range(G)]
             recv = torch.empty((G * (hi - lo), 2, k), dtype=torch.int32, device=val.device)
@@ -201,14 +201,14 @@ class ShardedKnn:
         buf, work = pending
         if work is not None:
             work.wait()
+        if self.solo:
+            val, idx = buf
+            return self.ops.vote(val, idx, feature_labels, classes, knn_t)
         if buf.shape[1] == 0:
             return torch.empty((0, classes), dtype=torch.int64, device=buf.device)
         val = buf[:, :, 0, :].contiguous().view(torch.float32)
         idx = buf[:, :, 1, :].to(torch.int64)
-        if not self.solo:
-            val, idx = self.ops.merge(val, idx, k)
-        else:
-            val, idx = val[0], idx[0]
+        val, idx = self.ops.merge(val, idx, k)
         return self.ops.vote(val, idx, feature_labels, classes, knn_t)
 
     @torch.no_grad()
