@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--query-chunk", type=int, default=16384)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the query chunks alternate between")
+    ap.add_argument("--shard", choices=["rows", "queries"], default="rows",
+                    help="rows: the bank is row-sharded (north star, default).  queries: comparison row of SURVEY 8(e) -- "
+                         "every rank holds the whole bank and serves a slice of the queries, no candidate exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -113,15 +116,19 @@ def main():
     _lib.lib()
 
     B, N, D, C, k, T = args.queries, args.bank, args.dim, args.classes, args.k, args.temperature
-    lo, hi = sharded.shard_bounds(N, world, rank)
-    bank_rows = unit_rows(hi - lo, D, 1000 + rank, device)                 # this rank's shard, [n_local, D] f32
+    by_rows = args.shard == "rows"
+    lo, hi = sharded.shard_bounds(N, world, rank) if by_rows else (0, N)
+    bank_rows = unit_rows(hi - lo, D, 1000 + (rank if by_rows else 0), device)   # this rank's shard (or the whole bank), [n_local, D] f32
     feature = unit_rows(B, D, 1, device)                                   # replicated queries
     labels = torch.randint(0, C, (N,), generator=torch.Generator(device=device).manual_seed(2), device=device)
     torch.cuda.synchronize()
 
     def step():
-        knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk,
-                                 n_streams=args.streams)
+        if by_rows:
+            knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk,
+                                     n_streams=args.streams)
+        else:
+            knn = sharded.QuerySlicedKnn(bank_rows, compute_dtype=args.dtype, query_chunk=args.query_chunk)
         top1 = knn.predict(feature, labels, C, k, T, gather="top1")
         return top1, knn.local_ranking
 
@@ -176,9 +183,11 @@ def main():
             "config": {
                 "workload": f"BASELINE configs[3]: kNN monitor, {B} queries x {N}x{D} bank, k={k}, T={T}, "
                             f"{C} classes, {args.dtype} MFMA with fp32 accumulate; step = pack + fused sim/top-k"
-                            f"{' + RCCL candidate all-to-all + merge' if world > 1 else ''} + vote + ranking",
+                            f"{' + RCCL candidate all-to-all + merge' if world > 1 and by_rows else ''} + vote + ranking",
                 "queries": B, "bank_rows": N, "dim": D, "k": k, "classes": C,
-                "parallelism": f"bank rows sharded over {world} GPU(s); merge/vote sharded by query slice; top-1 labels all-gathered",
+                "parallelism": (f"bank rows sharded over {world} GPU(s); merge/vote sharded by query slice; top-1 labels all-gathered"
+                                if by_rows else
+                                f"comparison row: whole bank on each of {world} GPU(s), queries sliced, no candidate exchange; top-1 labels all-gathered"),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -31,7 +31,7 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "ShardedKnn", "HipOps"]
+__all__ = ["shard_bounds", "ShardedKnn", "QuerySlicedKnn", "HipOps"]
 
 
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -288,6 +288,57 @@ class ShardedKnn:
             for j, (lo, hi) in enumerate(pc):
                 out[s + lo:s + hi] = allr[j, offs[j]:offs[j] + (hi - lo)]
                 offs[j] += hi - lo
+        return out if gather == "full" else out[:, 0].contiguous()
+
+
+class QuerySlicedKnn:
+    """The comparison row of SURVEY.md 8(e): every rank holds the WHOLE bank and serves a contiguous slice of the
+    queries -- no candidate exchange at all, only the final all-gather of the results.  Not the default: the north
+    star prescribes row sharding (and a bank that outgrows one GPU needs it); this form exists so that
+    ``bench.py --shard queries`` can put a number beside it.  Results are identical to the single-device path."""
+
+    def __init__(self, bank_rows: torch.Tensor, group=None, ops=None, compute_dtype=None, query_chunk: int = 8192):
+        self.group = group
+        self.world = dist.get_world_size(group) if _dist_on() else 1
+        self.rank = dist.get_rank(group) if _dist_on() else 0
+        self.ops = ops if ops is not None else HipOps(compute_dtype)
+        self.bank = self.ops.build_bank(bank_rows, 0)
+        self.n_total = int(self.ops.bank_rows(self.bank))
+        self.query_chunk = int(query_chunk)
+
+    @torch.no_grad()
+    def predict(self, feature, feature_labels, classes, knn_k, knn_t, gather: str = "full"):
+        if gather not in ("full", "top1"):
+            raise ValueError("gather must be 'full' or 'top1'")
+        k, classes, knn_t = int(knn_k), int(classes), float(knn_t)
+        if k > self.n_total:
+            raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
+        B, G = feature.shape[0], self.world
+        lo, hi = shard_bounds(B, G, self.rank)
+        parts = []
+        for s in range(lo, hi, self.query_chunk):
+            val, idx = self.ops.topk(feature[s:min(s + self.query_chunk, hi)], self.bank, k)
+            parts.append(self.ops.vote(val, idx, feature_labels, classes, knn_t))
+        mine = torch.cat(parts, 0) if parts else torch.empty((0, classes), dtype=torch.int64, device=feature.device)
+        self.local_rows = torch.arange(lo, hi, device=feature.device)
+        self.local_ranking = mine
+        if gather == "top1":
+            mine = mine[:, :1]
+        if G == 1:
+            return mine if gather == "full" else mine[:, 0].contiguous()
+        width = mine.shape[1]
+        longest = shard_bounds(B, G, 0)[1]                          # rank 0 holds the longest slice
+        padded = torch.zeros((longest, width), dtype=torch.int64, device=mine.device)
+        padded[:mine.shape[0]] = mine
+        if dist.get_backend(self.group) == "nccl":
+            allr = torch.empty((G * longest, width), dtype=torch.int64, device=mine.device)
+            dist.all_gather_into_tensor(allr, padded, group=self.group)
+            allr = allr.view(G, longest, width)
+        else:
+            got = [torch.empty_like(padded.cpu()) for _ in range(G)]
+            dist.all_gather(got, padded.cpu(), group=self.group)
+            allr = torch.stack(got).to(mine.device)
+        out = torch.cat([allr[j, :shard_bounds(B, G, j)[1] - shard_bounds(B, G, j)[0]] for j in range(G)], 0)
         return out if gather == "full" else out[:, 0].contiguous()
 
 

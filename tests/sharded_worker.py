@@ -66,6 +66,11 @@ def main(rank, world, port, use_gpu, out_dir):
         pred = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T)
         top1 = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T, gather="top1")
         assert torch.equal(knn.local_ranking, pred[knn.local_rows])     # the owner's slices are the full result's rows
+        # comparison row of SURVEY 8(e): whole bank on every rank, queries sliced, no candidate exchange
+        qs = sh.QuerySlicedKnn(torch.from_numpy(x).to(dev), ops=ops, compute_dtype="fp32", query_chunk=16)
+        qpred = qs.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T)
+        qtop1 = qs.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T, gather="top1")
+        assert torch.equal(qpred, pred) and torch.equal(qtop1, top1)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), val=val.cpu().numpy(), idx=idx.cpu().numpy(),
                  pred=pred.cpu().numpy(), top1=top1.cpu().numpy(), local_rows=knn.local_rows.cpu().numpy())
         # MemoryBank.push all-gathers the keys of every rank first (memory_bank.py:64)
