@@ -163,6 +163,46 @@ __global__ __launch_bounds__(256) void append_normalized_kernel(const float *__r
     for (int c = lane; c < (int)ld; c += 64) o[c] = (OutT)(c < D ? x[c] / denom : 0.f);
 }
 
+// Vector path: D % 4 == 0, D <= 2048, 16-byte aligned rows.  The row is read ONCE (8 x float4 per lane stay in
+// registers between the norm and the scaled store) and written with 8-/16-byte stores: 2.6 -> ~4.5 TB/s.
+template <typename OutT>
+__global__ __launch_bounds__(256) void append_normalized_vec_kernel(const float *__restrict__ src, long long ld_src,
+                                                                    long long b, int D, OutT *__restrict__ bank,
+                                                                    long long ld, long long row0, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= b) return;
+    const float4 *x = (const float4 *)(src + r * ld_src);
+    const int nv = D >> 2, nvo = (int)(ld >> 2);
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (j * 64 + lane) < nv ? x[j * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, ss))));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d, 64);
+    const float denom = fmaxf(sqrtf(ss), eps);                      // F.normalize: v / max(||v||_2, eps)
+    OutT *o = bank + (row0 + r) * ld;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = j * 64 + lane;
+        if (c < nvo) {                                              // columns D .. ld are zero padding
+            const bool in = c < nv;                                 // padding stays exactly 0 (even for 0 / 0 rows with eps = 0)
+            const float a0 = in ? v[j].x / denom : 0.f, a1 = in ? v[j].y / denom : 0.f;
+            const float a2 = in ? v[j].z / denom : 0.f, a3 = in ? v[j].w / denom : 0.f;
+            if constexpr (sizeof(OutT) == 4) {
+                ((float4 *)o)[c] = make_float4(a0, a1, a2, a3);
+            } else {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+                bf16x4_t w = {(__bf16)a0, (__bf16)a1, (__bf16)a2, (__bf16)a3};
+                ((bf16x4_t *)o)[c] = w;
+            }
+        }
+    }
+}
+
 __global__ void init_state_kernel(float *tau, int *topk_n, unsigned *big_cnt, unsigned *tmask, int mask_words, int B, int B_pad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,7 +529,11 @@ int mi_bank_append_normalized(const float *src, int64_t ld_src, int64_t b, int64
     if (!(eps >= 0.f)) return fail(MI_ERR_ARG, "mi_bank_append_normalized: eps must be non-negative");
     if (b == 0) return MI_OK;
     const dim3 grid((unsigned)ceil_div(b, 4));
-    if (dtype == MI_BF16) hipLaunchKernelGGL((append_normalized_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (__bf16 *)bank, ld, row0, eps);
+    const bool vec = D % 4 == 0 && ld <= 2048 && ld_src % 4 == 0 && (((uintptr_t)src | (uintptr_t)bank) & 15) == 0;   // ld % 32 == 0 already
+    if (vec) {
+        if (dtype == MI_BF16) hipLaunchKernelGGL((append_normalized_vec_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (__bf16 *)bank, ld, row0, eps);
+        else hipLaunchKernelGGL((append_normalized_vec_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (float *)bank, ld, row0, eps);
+    } else if (dtype == MI_BF16) hipLaunchKernelGGL((append_normalized_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (__bf16 *)bank, ld, row0, eps);
     else hipLaunchKernelGGL((append_normalized_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, b, (int)D, (float *)bank, ld, row0, eps);
     HIP_CHECK(hipGetLastError());
     return MI_OK;
