@@ -449,6 +449,8 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
             if ((j * 64 + lane) < n_cur) keys[j * 64 + lane] = pk[j];
     }
     bool touched = false;
+    bool have_kth = false;                                         // SRC_DENSE: last_kth = smallest of the k kept keys
+    unsigned long long last_kth = 0ull;
     int pos = 0;
     while (pos < n_new) {
         const int room = WSEL_CAP - n_cur;
@@ -495,6 +497,31 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
                     }
                 }
             }
+        } else if (have_kth) {
+            // k keys are held and their smallest is known: of the next values only those above it can matter
+            // (in a random row as many as are held already), so they are filtered on the way into LDS -- 256
+            // values per round while a round's worst case (all 256 pass) still fits the room
+            const float *d = (const float *)p.cand + row * 2 * p.cap + pos;
+            const int left = n_new - pos;
+            int appended = 0, consumed = 0;
+            while (consumed < left && room - appended >= 256) {
+                const int i = consumed + 4 * lane;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < left) v = *(const float4 *)(d + i);
+                const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long key = (i + u < left) ? make_key(f[u], (unsigned)(p.dense_col0 + pos + i + u)) : 0ull;
+                    const bool pass = key > last_kth;
+                    const unsigned long long bal = __ballot(pass);
+                    if (pass) keys[n_cur + appended + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+                    appended += __popcll(bal);
+                }
+                consumed += 256;
+            }
+            m = appended;
+            step = consumed < left ? consumed : left;
+            nz = lane == 0 ? appended : 0;
         } else {
             m = (n_new - pos) < room ? (n_new - pos) : (room & ~3);     // pos stays a multiple of 4: 16-byte loads
             step = m;
@@ -529,6 +556,7 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
         const int keep = nz < p.k ? nz : p.k;
         unsigned long long kth = 1ull;                             // nz <= k: keep every real key
         if (nz > keep) kth = wave_radix_select_kth(sm, tot, keep, lane);
+        if (SRC == SRC_DENSE && nz > keep) { have_kth = true; last_kth = kth; }      // keep == k here
         wave_step();
         // ordered in-place compaction of the `keep` keys >= kth (they are distinct): a chunk is read before it
         // is written, and writes never reach a chunk not yet read
