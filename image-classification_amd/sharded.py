@@ -31,7 +31,7 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "ShardedKnn", "QuerySlicedKnn", "HipOps"]
+__all__ = ["shard_bounds", "chunk_bounds", "ShardedKnn", "QuerySlicedKnn", "HipOps"]
 
 
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -39,6 +39,17 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     base, extra = divmod(int(n_total), int(world))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def chunk_bounds(n: int, chunk: int):
+    """[lo, hi) query ranges of about ``chunk`` rows.  A short tail (< chunk / 4) is folded into the last
+    chunk: a GEMM over a few hundred queries runs far below the rate of a full one and still pays every
+    stage's refresh (50 000 = 16384 + 16384 + 17232, not ... + 848)."""
+    n, chunk = int(n), int(chunk)
+    lows = list(range(0, n, chunk))
+    if len(lows) > 1 and n - lows[-1] < chunk // 4:
+        lows.pop()
+    return [(lo, lows[i + 1] if i + 1 < len(lows) else n) for i, lo in enumerate(lows)]
 
 
 class HipOps:
@@ -136,7 +147,7 @@ class ShardedKnn:
         if k > self.n_total:
             raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
         B = feature.shape[0]
-        starts = list(range(0, B, self.query_chunk))
+        starts = chunk_bounds(B, self.query_chunk)
         side = _side_streams(feature.device, self.n_streams) if (feature.is_cuda and len(starts) > 1) else None
         main = torch.cuda.current_stream(feature.device) if side else None
         outs = [None] * len(starts)
@@ -145,11 +156,11 @@ class ShardedKnn:
         def on_stream(i):
             return torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()
 
-        for i, s in enumerate(starts):
+        for i, (s, e) in enumerate(starts):
             if side and i < len(side):
                 side[i].wait_stream(main)                # inputs were produced on the caller's stream
             with on_stream(i):
-                val, idx = self._local_candidates(feature[s:s + self.query_chunk], k)
+                val, idx = self._local_candidates(feature[s:e], k)
                 nxt = self._exchange(val, idx)           # chunk i's all-gather runs beside the next chunk's GEMM
             if pending is not None:
                 with on_stream(pending[0]):
@@ -231,7 +242,7 @@ class ShardedKnn:
         if self.n_total >= 2 ** 31:
             raise ValueError("the candidate exchange carries int32 global rows: N must be < 2^31")
         B, G = feature.shape[0], self.world
-        starts = list(range(0, B, self.query_chunk))
+        starts = chunk_bounds(B, self.query_chunk)
         slices, rows = [None] * len(starts), []
         # n_streams > 1: query chunks alternate between side streams, so the threshold refreshes, launch gaps,
         # exchange, merge and vote of one chunk run beside the other chunk's GEMM (pays when the shard is small)
@@ -243,10 +254,10 @@ class ShardedKnn:
             return torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()
 
         pending = None                                   # (chunk number, exchange in flight)
-        for i, s in enumerate(starts):
+        for i, (s, e) in enumerate(starts):
             if side and i < len(side):
                 side[i].wait_stream(main)                # inputs were produced on the caller's stream
-            f = feature[s:s + self.query_chunk]
+            f = feature[s:e]
             with on_stream(i):
                 val, idx = self._local_candidates(f, k)
                 nxt = self._to_owners(val, idx)          # chunk i's exchange runs beside the next chunk's GEMM
@@ -270,7 +281,7 @@ class ShardedKnn:
         # final gather: pad every rank's slice to the same length, then undo the (chunk, owner) interleave
         mine = self.local_ranking if gather == "full" else self.local_ranking[:, :1]
         width = mine.shape[1]
-        per_chunk = [[shard_bounds(min(self.query_chunk, B - s), G, j) for j in range(G)] for s in starts]
+        per_chunk = [[shard_bounds(e - s, G, j) for j in range(G)] for s, e in starts]
         longest = max(sum(hi - lo for lo, hi in (pc[j] for pc in per_chunk)) for j in range(G))
         padded = torch.zeros((longest, width), dtype=torch.int64, device=mine.device)
         padded[:mine.shape[0]] = mine
@@ -284,7 +295,7 @@ class ShardedKnn:
             allr = torch.stack(parts).to(mine.device)
         out = torch.empty((B, width), dtype=torch.int64, device=mine.device)
         offs = [0] * G
-        for s, pc in zip(starts, per_chunk):
+        for (s, _), pc in zip(starts, per_chunk):
             for j, (lo, hi) in enumerate(pc):
                 out[s + lo:s + hi] = allr[j, offs[j]:offs[j] + (hi - lo)]
                 offs[j] += hi - lo
@@ -316,8 +327,8 @@ class QuerySlicedKnn:
         B, G = feature.shape[0], self.world
         lo, hi = shard_bounds(B, G, self.rank)
         parts = []
-        for s in range(lo, hi, self.query_chunk):
-            val, idx = self.ops.topk(feature[s:min(s + self.query_chunk, hi)], self.bank, k)
+        for s, e in chunk_bounds(hi - lo, self.query_chunk):
+            val, idx = self.ops.topk(feature[lo + s:lo + e], self.bank, k)
             parts.append(self.ops.vote(val, idx, feature_labels, classes, knn_t))
         mine = torch.cat(parts, 0) if parts else torch.empty((0, classes), dtype=torch.int64, device=feature.device)
         self.local_rows = torch.arange(lo, hi, device=feature.device)
