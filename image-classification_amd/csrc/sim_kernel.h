@@ -101,12 +101,6 @@ __device__ __forceinline__ float row16_sum(float v)
 #ifndef MI_PF_DIST
 #define MI_PF_DIST 2
 #endif
-#ifndef MI_PF_ALL
-#define MI_PF_ALL 0
-#endif
-#ifndef MI_PF_RED2
-#define MI_PF_RED2 0
-#endif
 #ifndef MI_PF_POS
 #define MI_PF_POS 4
 #endif
@@ -211,38 +205,22 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     // ---- L2 prefetch.  The 32 workgroups of an XCD patch stream the same 8 + 4 operand tiles, so 19 % of the
     // DMA requests -- the first touch of every line in this XCD -- miss the L2 and take the Infinity-Cache
     // latency, which a two-buffer pipeline cannot hide (one K-step of lead).  Each workgroup therefore touches
-    // its share of the lines of the K-step AFTER next (A tile: 4 sharers x 64 rows, B tile: 8 sharers x 32 rows
-    // = 96 lines, 12 per wave) with a plain dword load into a register nobody reads: the DMA one step later hits.
+    // its share of the lines of the K-step AFTER next (8 x 4 patch: A tile 4 sharers x 64 rows, B tile 8 sharers
+    // x 32 rows = 96 lines, 12 per wave; narrower patches share less and touch more) with a plain dword load
+    // into a register nobody reads: the DMA one step later hits.
     const char *pf_src;
     {
-#if MI_PF_ALL
-        const int idx = w * 64 + lane;                      // experiment: every workgroup touches all its own lines
-        if (idx < 256) {
-            int r = q0 + idx; r = r < p.B ? r : p.B - 1;
+        const int la = TILE >> (5 - p.qsh), lb = TILE >> p.qsh;        // A / B rows this workgroup touches
+        const int per = (la + lb + 7) >> 3;                            // lines per wave (12 .. 33)
+        int idx = w * per + (lane % per);
+        idx = idx < la + lb ? idx : la + lb - 1;
+        if (idx < la) {
+            int r = q0 + la * (inner >> p.qsh) + idx; r = r < p.B ? r : p.B - 1;
             pf_src = p.q + (long long)r * p.ldq_bytes;
         } else {
-            int r = n0 + idx - 256; r = r < p.N ? r : p.N - 1;
+            int r = n0 + lb * (inner & ((1 << p.qsh) - 1)) + (idx - la); r = r < p.N ? r : p.N - 1;
             pf_src = p.x + (long long)r * p.ldx_bytes;
         }
-#elif MI_PF_RED2
-        const int idx = w * 24 + (lane % 24);               // experiment: every line touched by two of its sharers
-        if (idx < 128) {
-            int r = q0 + 128 * ((inner >> 3) & 1) + idx; r = r < p.B ? r : p.B - 1;
-            pf_src = p.q + (long long)r * p.ldq_bytes;
-        } else {
-            int r = n0 + 64 * (inner & 3) + (idx - 128); r = r < p.N ? r : p.N - 1;
-            pf_src = p.x + (long long)r * p.ldx_bytes;
-        }
-#else
-        const int idx = w * 12 + (lane % 12);
-        if (idx < 64) {
-            int r = q0 + 64 * ((inner >> 3) & 3) + idx; r = r < p.B ? r : p.B - 1;
-            pf_src = p.q + (long long)r * p.ldq_bytes;
-        } else {
-            int r = n0 + 32 * (inner & 7) + (idx - 64); r = r < p.N ? r : p.N - 1;
-            pf_src = p.x + (long long)r * p.ldx_bytes;
-        }
-#endif
     }
     unsigned pf_sink = 0u;                                  // stays live across the K loop: the register is reserved
     auto prefetch = [&](int t) {
