@@ -282,3 +282,25 @@ def test_rccl_branches_on_one_rank_group(ica):
         assert torch.equal(v, v_ref) and torch.equal(i, i_ref)
     finally:
         dist.destroy_process_group()
+
+
+_SWEEP = [(B, N, D, k) for B, N, D, k in [
+    (5, 2048, 32, 1), (70, 2049, 32, 63), (33, 2300, 64, 64), (257, 4097, 32, 65), (64, 9001, 96, 255), (129, 8193, 32, 256),
+    (31, 12345, 64, 257), (700, 3000, 32, 200), (16, 70000, 32, 200), (300, 2047, 36, 199), (2, 300, 20, 300), (90, 26000, 256, 100)]]
+
+
+@pytest.mark.parametrize("B,N,D,k", _SWEEP)
+def test_fp32_shape_sweep_bit_exact(ica, B, N, D, k):
+    """Odd shapes around every boundary of the refresh kernels (k at 1 / 63-65 / 255-257: wave-per-row vs
+    workgroup select; N at 2047-2049: bootstrap only vs one filter stage; ragged tiles; D with padding), with a
+    clustered bank so that many rows carry far more than 64 candidates per stage: values and indices bit-equal to
+    the chain oracle."""
+    rs = np.random.RandomState(B * 7 + N + k)
+    centers = rs.randn(8, D)
+    f = ko.l2_normalize(centers[rs.randint(0, 8, size=B)] + 0.3 * rs.randn(B, D))
+    x = ko.l2_normalize(centers[rs.randint(0, 8, size=N)] + 0.3 * rs.randn(N, D))
+    x[N // 2:N // 2 + 5] = x[:5]                                  # exact ties, lower row first
+    sim = chain.sim_chain_f32(f, x)
+    v_ref, i_ref = chain.topk_rows(sim, k)
+    v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), k)
+    assert np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
