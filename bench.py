@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--shard", choices=["rows", "queries"], default="rows",
                     help="rows: the bank is row-sharded (north star, default).  queries: comparison row of SURVEY 8(e) -- "
                          "every rank holds the whole bank and serves a slice of the queries, no candidate exchange")
+    ap.add_argument("--data", choices=["random", "clustered", "clustered-sorted"], default="random",
+                    help="random: N(0,1) rows, L2-normalised (the metric's workload).  clustered: class centroid + 0.5 N(0,1) "
+                         "(SURVEY 8d realism variant); clustered-sorted: the same with the bank in class order (an ImageFolder memo loader)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -70,6 +73,18 @@ def unit_rows(n, d, seed, device, chunk=65536):
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         x = torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
+        out[s:e] = torch.nn.functional.normalize(x, dim=1)
+    return out
+
+
+def clustered_rows(labels, d, centroids, seed, device, chunk=65536):
+    """[n, d] float32 rows: normalise(centroid[label] + 0.5 N(0,1)), generated on device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = labels.numel()
+    out = torch.empty((n, d), dtype=torch.float32, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        x = centroids[labels[s:e]] + 0.5 * torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
         out[s:e] = torch.nn.functional.normalize(x, dim=1)
     return out
 
@@ -118,9 +133,17 @@ def main():
     B, N, D, C, k, T = args.queries, args.bank, args.dim, args.classes, args.k, args.temperature
     by_rows = args.shard == "rows"
     lo, hi = sharded.shard_bounds(N, world, rank) if by_rows else (0, N)
-    bank_rows = unit_rows(hi - lo, D, 1000 + (rank if by_rows else 0), device)   # this rank's shard (or the whole bank), [n_local, D] f32
-    feature = unit_rows(B, D, 1, device)                                   # replicated queries
     labels = torch.randint(0, C, (N,), generator=torch.Generator(device=device).manual_seed(2), device=device)
+    if args.data == "random":
+        bank_rows = unit_rows(hi - lo, D, 1000 + (rank if by_rows else 0), device)   # this rank's shard (or the whole bank), [n_local, D] f32
+        feature = unit_rows(B, D, 1, device)                               # replicated queries
+    else:
+        if args.data == "clustered-sorted":
+            labels = labels.sort().values
+        centroids = torch.randn((C, D), generator=torch.Generator(device=device).manual_seed(3), device=device)
+        bank_rows = clustered_rows(labels[lo:hi], D, centroids, 1000 + (rank if by_rows else 0), device)
+        qlab = torch.randint(0, C, (B,), generator=torch.Generator(device=device).manual_seed(4), device=device)
+        feature = clustered_rows(qlab, D, centroids, 1, device)
     torch.cuda.synchronize()
 
     def step():
@@ -179,7 +202,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.data == "random" else f"synthetic ({args.data})",
             "config": {
                 "workload": f"BASELINE configs[3]: kNN monitor, {B} queries x {N}x{D} bank, k={k}, T={T}, "
                             f"{C} classes, {args.dtype} MFMA with fp32 accumulate; step = pack + fused sim/top-k"
