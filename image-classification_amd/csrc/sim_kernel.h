@@ -37,7 +37,7 @@ constexpr int KSTEP_BYTES = 128;          // bytes of one row per K-step
 constexpr int OPERAND_TILE_BYTES = TILE * KSTEP_BYTES;       // 32 KiB
 constexpr int STAGE_BYTES = 2 * OPERAND_TILE_BYTES;          // A + B
 constexpr int SIM_LDS_BYTES = 2 * STAGE_BYTES;               // double buffered: 128 KiB
-constexpr int SIM_EXTRA_LDS = 2048;                         // thresholds + candidate counters of the tile's 256 rows
+constexpr int SIM_EXTRA_LDS = 2048 + 256;                   // thresholds + candidate counters of the tile's 256 rows, prefetch sink
 constexpr int SIM_THREADS = 512;
 constexpr int PATCH_Q = 8, PATCH_N = 4;   // tiles of one XCD patch (8 query tiles x 4 bank tiles)
 
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     // DMA requests -- the first touch of every line in this XCD -- miss the L2 and take the Infinity-Cache
     // latency, which a two-buffer pipeline cannot hide (one K-step of lead).  Each workgroup therefore touches
     // its share of the lines of the K-step AFTER next (8 x 4 patch: A tile 4 sharers x 64 rows, B tile 8 sharers
-    // x 32 rows = 96 lines, 12 per wave; narrower patches share less and touch more) with a plain dword load
-    // into a register nobody reads: the DMA one step later hits.
+    // x 32 rows = 96 lines, 12 per wave; narrower patches share less and touch more) with a dword load nobody waits
+    // for: the DMA one step later hits.
     const char *pf_src;
     {
         const int la = TILE >> (5 - p.qsh), lb = TILE >> p.qsh;        // A / B rows this workgroup touches
@@ -222,10 +222,17 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             pf_src = p.x + (long long)r * p.ldx_bytes;
         }
     }
-    unsigned pf_sink = 0u;                                  // stays live across the K loop: the register is reserved
+    // The touch is an LDS-DMA dword load into 256 spare bytes of LDS that nothing reads: no destination register
+    // exists that the compiler could reuse while the load is still in flight.
+    const unsigned pf_lds = (unsigned)(size_t)(AS3 char *)(smem + SIM_LDS_BYTES + 2048);
     auto prefetch = [&](int t) {
         t = t < p.ksteps ? t : p.ksteps - 1;                // never past the end of a row
-        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_src + (long long)t * KSTEP_BYTES) : "memory");
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[a], off\n\ts_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [l] "s"(pf_lds), [a] "v"(pf_src + (long long)t * KSTEP_BYTES)
+            : "memory");
     };
 #else
     auto prefetch = [&](int) {};
@@ -389,8 +396,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{});
     if (p.ksteps > 1) kstep(p.ksteps - 2, std::true_type{}, std::false_type{});
     kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" ::"v"(pf_sink));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the last touches have landed before LDS is reused
 #else
     for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{}, std::false_type{});
     kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
