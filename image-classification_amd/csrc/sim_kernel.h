@@ -6,8 +6,10 @@
 //   MODE_DENSE  : bootstrap stage -- the tile is stored densely (values only) into the per-row
 //                 candidate buffer, the select kernel turns it into the first top-k + threshold;
 //   MODE_FILTER : every element is compared with its row's threshold tau[row] (a lower bound of
-//                 the row's final k-th largest similarity); survivors (rare) are appended to the
-//                 row's candidate list in HBM through one atomic slot counter per row;
+//                 the row's final k-th largest similarity); survivors (rare) go straight to the
+//                 (row, bank tile) segment of the row's candidate buffer in HBM -- slot from an LDS
+//                 counter, per-tile counts and a per-row tile bitmask tell the refresh kernels
+//                 where to look, no returning global atomic;
 //   MODE_LSE    : MoCo logits -- per-row (max, sum exp) partials of sim / T over the tile's columns.
 //
 // Data layout: both operands are K-contiguous rows ([rows, ld] elements, a row = whole 128-byte
