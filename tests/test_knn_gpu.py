@@ -304,3 +304,27 @@ def test_fp32_shape_sweep_bit_exact(ica, B, N, D, k):
     v_ref, i_ref = chain.topk_rows(sim, k)
     v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), k)
     assert np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+
+
+def test_knn_predict_replays_from_a_hip_graph(ica):
+    """The whole monitor pass (query pack, bootstrap, every filter stage and refresh, vote, ranking) is stream
+    ordered -- no host synchronisation, no allocation inside the library -- so it captures into a HIP graph
+    (torch.cuda.CUDAGraph) and replays on new query values with the eager result, bit for bit."""
+    f, x, lab = _rand_case(600, 20000, 64, 10, 77)
+    f2 = _rand_case(600, 20000, 64, 10, 78)[0]
+    bank = ica.BankIndex.from_rows(dev(x), "bf16")
+    labels = dev(lab)
+    fin = dev(f)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                  # warm-up outside the capture (library load, allocator)
+        ica.knn_predict(fin, bank, labels, 10, 200, 0.1)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ica.knn_predict(fin, bank, labels, 10, 200, 0.1)
+    for feats in (f, f2):
+        fin.copy_(dev(feats))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ica.knn_predict(dev(feats), bank, labels, 10, 200, 0.1))
