@@ -456,46 +456,56 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
         const int room = WSEL_CAP - n_cur;
         int m, step, nz = 0;
         if constexpr (SRC == SRC_LIST) {
-            // the longest run of tiles from `pos` (one per lane) whose candidates fit the room (a tile holds
-            // <= 256, room >= 768: progress)
-            const int t = pos + lane;
-            int c = 0;
-            if (t < n_new && ((p.tmask[row * p.mask_words + (t >> 5)] >> (t & 31)) & 1u))
-                c = (int)p.cnt2[(long long)t * p.bpad + row];
-            int incl = c;
+            // Runs of 64 tiles (one per lane) are appended while their candidates fit the room; the select below
+            // runs once per filled batch, not once per run: a stage of several launches has thousands of tiles,
+            // most of them empty for a given row (a tile holds <= 256, room >= 768: progress).
+            const unsigned *tm = p.tmask + row * p.mask_words;
+            m = 0;
+            step = 0;
+            for (;;) {
+                const int p0 = pos + step;
+                if (p0 >= n_new) break;
+                const int t = p0 + lane;
+                int c = 0;
+                if (t < n_new && ((tm[t >> 5] >> (t & 31)) & 1u)) c = (int)p.cnt2[(long long)t * p.bpad + row];
+                int incl = c;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            const bool fits = t < n_new && incl <= room;
-            step = __popcll(__ballot(fits));                       // a prefix of the lanes: incl is monotone
-            m = __shfl(incl, step - 1, 64);
-            if (fits && c) {
-                // 8 candidates (4 x 16 bytes) in flight per lane; slot c of an odd count is read (inside the
-                // segment) and ignored
-                const uint4 *seg = (const uint4 *)(p.cand + row * p.cap + (long long)t * 256);
-                unsigned long long *dst = keys + n_cur + incl - c;
-                for (int e0 = 0; e0 < c; e0 += 8) {
-                    uint4 v[4];
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                const bool fits = t < n_new && incl <= room - m;
+                const int took = __popcll(__ballot(fits));          // a prefix of the lanes: incl is monotone
+                if (took == 0) break;
+                if (fits && c) {
+                    // 8 candidates (4 x 16 bytes) in flight per lane; slot c of an odd count is read (inside the
+                    // segment) and ignored
+                    const uint4 *seg = (const uint4 *)(p.cand + row * p.cap + (long long)t * 256);
+                    unsigned long long *dst = keys + n_cur + m + incl - c;
+                    for (int e0 = 0; e0 < c; e0 += 8) {
+                        uint4 v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (e0 + 2 * j < c) v[j] = seg[(e0 >> 1) + j];
+                        for (int j = 0; j < 4; ++j)
+                            if (e0 + 2 * j < c) v[j] = seg[(e0 >> 1) + j];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int e = e0 + 2 * j;
-                        if (e < c) {
-                            const unsigned long long key = make_key(__uint_as_float(v[j].x), v[j].y);
-                            dst[e] = key;
-                            nz += key != 0ull;
-                        }
-                        if (e + 1 < c) {
-                            const unsigned long long key = make_key(__uint_as_float(v[j].z), v[j].w);
-                            dst[e + 1] = key;
-                            nz += key != 0ull;
+                        for (int j = 0; j < 4; ++j) {
+                            const int e = e0 + 2 * j;
+                            if (e < c) {
+                                const unsigned long long key = make_key(__uint_as_float(v[j].x), v[j].y);
+                                dst[e] = key;
+                                nz += key != 0ull;
+                            }
+                            if (e + 1 < c) {
+                                const unsigned long long key = make_key(__uint_as_float(v[j].z), v[j].w);
+                                dst[e + 1] = key;
+                                nz += key != 0ull;
+                            }
                         }
                     }
                 }
+                m += __shfl(incl, took - 1, 64);
+                step += took;
+                if (p0 + took < n_new && took < 64) break;          // the room is used up: select, then go on from here
             }
         } else if (have_kth) {
             // k keys are held and their smallest is known: of the next values only those above it can matter
@@ -548,6 +558,7 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
                 }
             }
         }
+        if (m == 0) { pos += step; continue; }                     // no candidate in the tiles consumed: nothing to select
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d, 64);
         wave_step();
