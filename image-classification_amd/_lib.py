@@ -12,11 +12,11 @@ LIB_PATH = os.environ.get("MI_KNN_LIB") or os.path.join(HERE, "libmi_knn.so")   
 
 MI_F32, MI_BF16 = 0, 1
 MI_MAX_K, MI_MAX_CLASSES = 1024, 65536
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes",
-    "mi_knn_topk", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
+    "mi_knn_topk", "mi_knn_topk_static", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
     "mi_moco_fwd", "mi_moco_bwd", "mi_queue_push_stash", "mi_bank_append_normalized", "mi_queue_push_wrap", "mi_soft_knn_workspace_bytes", "mi_soft_knn", "mi_kth_largest",
 ]
 
@@ -52,6 +52,8 @@ def lib() -> ctypes.CDLL:
     L.mi_knn_topk_workspace_bytes.argtypes = [i64, i64, i32]
     L.mi_knn_topk.restype = i32
     L.mi_knn_topk.argtypes = [p, i64, p, i64, i32, i64, i64, i64, i32, i64, p, p, p, sz, p]
+    L.mi_knn_topk_static.restype = i32
+    L.mi_knn_topk_static.argtypes = [p, i64, p, i64, i32, i64, i64, i64, i32, i64, p, p, p]
     L.mi_knn_merge.restype = i32
     L.mi_knn_merge.argtypes = [p, p, i32, i64, i32, i32, p, p, p]
     L.mi_knn_vote.restype = i32

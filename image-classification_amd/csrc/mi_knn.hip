@@ -545,10 +545,14 @@ size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k)
     return make_plan(B, N, k, -1).total + 2048 + 4 * (size_t)round_up(B, mi::TILE);        // + the alignment slack make_plan reserves when it sizes from a byte count
 }
 
-int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
-                int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
-                float *out_val, int64_t *out_idx,
-                void *workspace, size_t workspace_bytes, mi_stream_t stream)
+}  // extern "C"
+
+namespace {
+// Body of mi_knn_topk and mi_knn_topk_static: the two differ only in where the workspace lives.
+int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
+                  int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
+                  float *out_val, int64_t *out_idx,
+                  void *workspace, size_t workspace_bytes, mi_stream_t stream)
 {
     if (!q || !bank || !out_val || !out_idx || !workspace) return fail(MI_ERR_ARG, "mi_knn_topk: null pointer");
     if (dtype != MI_F32 && dtype != MI_BF16) return fail(MI_ERR_ARG, "mi_knn_topk: bad dtype %d", dtype);
@@ -664,6 +668,63 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
         }
     }
     return MI_OK;
+}
+
+// ---- scratch of mi_knn_topk_static: device memory that belongs to the code object, one copy per GPU.
+// In host code the array's NAME is only a handle for hipGetSymbolAddress; the address kernels and
+// memsets may use is the one that call returns, resolved once per device and kept here.
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)MI_KNN_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[MAX_DEVICES] = {};
+
+int static_scratch(void **out)
+{
+    int dev = -1;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(MI_ERR_UNSUPPORTED, "mi_knn_topk_static: device ordinal %d outside [0, %d)", dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));          // this device's copy of the array
+        if (!ptr) return fail(MI_ERR_HIP, "mi_knn_topk_static: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
+                int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
+                float *out_val, int64_t *out_idx,
+                void *workspace, size_t workspace_bytes, mi_stream_t stream)
+{
+    return knn_topk_impl(q, ldq, bank, ldb, dtype, B, N, D, k, idx_base, out_val, out_idx, workspace, workspace_bytes, stream);
+}
+
+int mi_knn_topk_static(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
+                       int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
+                       float *out_val, int64_t *out_idx, mi_stream_t stream)
+{
+    if (B <= 0 || N <= 0 || k < 1 || k > MI_MAX_K || B > (1 << 30) || N > INT32_MAX - 2 * mi::TILE)
+        return fail(MI_ERR_ARG, "mi_knn_topk_static: bad shape B=%lld N=%lld k=%d", (long long)B, (long long)N, k);
+    // the smallest workspace mi_knn_topk accepts for this shape must fit the fixed scratch array
+    const size_t fixed = make_plan(B, N, k, -1).fixed;
+    const Plan pl = make_plan(B, N, k, STATIC_SCRATCH_BYTES > fixed ? (int64_t)(STATIC_SCRATCH_BYTES - fixed) : 0);
+    if (pl.cap == 0 || pl.total > STATIC_SCRATCH_BYTES)
+        return fail(MI_ERR_WORKSPACE, "mi_knn_topk_static: B=%lld queries with k=%d need more than the %zu-byte static scratch "
+                    "(about 16.4 KiB + 8 k bytes per query row, rows rounded up to 256); use mi_knn_topk with a caller workspace",
+                    (long long)B, k, STATIC_SCRATCH_BYTES);
+    void *ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != MI_OK) return rc;
+    // every word the kernels expect to start at zero is cleared by init_state_kernel at the top of the pass,
+    // so the previous call's contents (this GPU's array keeps them) never leak into this one
+    return knn_topk_impl(q, ldq, bank, ldb, dtype, B, N, D, k, idx_base, out_val, out_idx, ws, STATIC_SCRATCH_BYTES, stream);
 }
 
 int mi_knn_merge(const float *cand_val, const int64_t *cand_idx, int G, int64_t B, int kc, int k,

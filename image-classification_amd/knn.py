@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
+__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_topk_static", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
            "pack_rows", "DEFAULT_COMPUTE_DTYPE"]
 
 # "fp32": exact float32 products, one k-ascending fma chain per similarity (the parity mode);
@@ -202,6 +202,29 @@ def knn_topk(feature: torch.Tensor, bank: BankIndex, k: int) -> Tuple[torch.Tens
                                  val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws_bytes,
                                  _lib.stream_ptr(dev)), "mi_knn_topk")
     return val, idx
+
+
+def knn_topk_static(q: PackedRows, bank: BankIndex, k: int, out_val: torch.Tensor, out_idx: torch.Tensor) -> None:
+    """``knn_topk`` for callers that cannot allocate (HIP graph capture, serving loops): ``mi_knn_topk_static``.
+
+    Nothing is allocated here or in the library: ``q`` are queries already packed by :func:`pack_rows` in the bank's
+    compute dtype, ``out_val`` [B, k] float32 and ``out_idx`` [B, k] int64 are the caller's buffers, and the
+    workspace is the library's fixed 64 MiB static scratch (about 18 KiB per query row at k = 200: B <= 3584).
+    Calls that overlap on one GPU share that scratch and race -- keep them on one stream."""
+    if not isinstance(q, PackedRows) or q.dtype_code != bank.packed.dtype_code or q.dim != bank.dim:
+        raise ValueError("q must be PackedRows of the bank's compute dtype and dimension (pack_rows)")
+    B, k = q.rows, int(k)
+    dev = q.data.device
+    for t, dt, name in ((out_val, torch.float32, "out_val"), (out_idx, torch.int64, "out_idx")):
+        if t.dtype != dt or tuple(t.shape) != (B, k) or not t.is_contiguous() or t.device != dev:
+            raise ValueError(f"{name} must be a contiguous [{B}, {k}] {dt} tensor on {dev}")
+    if k > bank.n:
+        raise RuntimeError(f"selected index k out of range (k={k} > N={bank.n})")
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mi_knn_topk_static(q.data.data_ptr(), q.ld, bank.packed.data.data_ptr(), bank.packed.ld,
+                                                 q.dtype_code, B, bank.n, bank.dim, k, bank.idx_base,
+                                                 out_val.data_ptr(), out_idx.data_ptr(), _lib.stream_ptr(dev)),
+                   "mi_knn_topk_static")
 
 
 def knn_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -88,6 +88,22 @@ int mi_knn_topk(const void *q, int64_t ldq, const void *bank, int64_t ldb, int d
                 int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
                 float *out_val, int64_t *out_idx,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* mi_knn_topk for callers that cannot allocate device memory.  No counterpart in the reference (pure torch,
+ * which allocates freely): it is for code under HIP graph capture, tight serving loops and harnesses that
+ * forbid hipMalloc -- they cannot provide the workspace mi_knn_topk asks for.  Same arguments, same kernels
+ * and bit-identical results; the workspace is a fixed MI_KNN_STATIC_SCRATCH_BYTES array inside the library's
+ * code object (`static __device__`, one copy per GPU, held until the process ends).  The call allocates and
+ * frees nothing (no hipMalloc/hipFree, no allocating library routine); the first call on a device resolves
+ * that device's address of the array with hipGetSymbolAddress (make that first call outside a graph capture).
+ * Limit: the smallest workspace of the shape must fit the array -- roughly 16.4 KiB + 8 k bytes per query row,
+ * rows rounded up to 256 (k = 200: B <= 3584) -- otherwise MI_ERR_WORKSPACE; N is not limited by it.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * serialise them.  Every word that must start at zero is cleared at the top of each call. */
+#define MI_KNN_STATIC_SCRATCH_BYTES (64u << 20)
+int mi_knn_topk_static(const void *q, int64_t ldq, const void *bank, int64_t ldb, int dtype,
+                       int64_t B, int64_t N, int64_t D, int k, int64_t idx_base,
+                       float *out_val, int64_t *out_idx, mi_stream_t stream);
 
 /* Deterministic merge of per-shard candidates (the step after the RCCL all-gather; no reference
  * counterpart -- the reference kNN is single-device).

@@ -35,6 +35,11 @@ def test_argument_validation_without_gpu():
     assert L.mi_knn_topk(None, 0, None, 0, 0, 1, 1, 1, 1, 0, None, None, None, 0, None) == -1
     assert b"null pointer" in L.mi_last_error()
     assert L.mi_queue_push(None, 1, 1, 0, None, 1, None, None) == -1
+    # the allocation-free variant rejects shapes beyond its fixed scratch before it touches the device
+    assert L.mi_knn_topk_static(None, 0, None, 0, 0, 3585, 100000, 128, 200, 0, None, None, None) == -3
+    assert b"static scratch" in L.mi_last_error()
+    assert L.mi_knn_topk_static(None, 0, None, 0, 0, 100000, 100000, 128, 1, 0, None, None, None) == -3
+    assert L.mi_knn_topk_static(None, 0, None, 0, 0, 0, 10, 128, 1, 0, None, None, None) == -1
     assert L.mi_knn_vote(None, None, None, 1, 1, 1, 1, 0.1, None, None, None) == -1
 
 
