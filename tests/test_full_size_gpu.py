@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import chain
+from oracle import knn_oracle as ko
 from tests import parity as P
 
 pytestmark = pytest.mark.gpu
@@ -141,3 +143,71 @@ def test_c5_oversized_bank_one_shard_fp32(ica):
     val, idx = ica.knn_topk(feature, ica.BankIndex.from_rows(bank_rows, "fp32", idx_base=base), k)
     check_rows_wellformed(val, idx - base, n_local)
     compare_sample(val, idx - base, feature, bank_rows, k, "fp32", n_sample=64)
+
+
+def test_c5_oversized_bank_full_size_eight_shards_fp32(ica):
+    """BASELINE configs[4] at its real size: the whole 10M x 256 fp32 bank (10.2 GB, it fits one MI355X) cut into the
+    eight row shards the 8-GPU job would hold, each searched with its global index base, then ``mi_knn_merge`` --
+    bit-equal to ONE unsharded ``mi_knn_topk`` over all 10M rows; plus the sampled torch recomputation."""
+    N, D, k, B, G = 10_000_000, 256, 200, 4096, 8
+    bank_rows = unit_rows(N, D, 6)
+    feature = unit_rows(B, D, 7)
+    v_ref, i_ref = ica.knn_topk(feature, ica.BankIndex.from_rows(bank_rows, "fp32"), k)
+    check_rows_wellformed(v_ref, i_ref, N)
+    sharded = ica.sharded
+    cv, ci = [], []
+    for g in range(G):
+        lo, hi = sharded.shard_bounds(N, G, g)
+        v, i = ica.knn_topk(feature, ica.BankIndex.from_rows(bank_rows[lo:hi], "fp32", idx_base=lo), k)
+        assert int(i.min()) >= lo and int(i.max()) < hi
+        cv.append(v)
+        ci.append(i)
+    mv, mi = ica.knn_merge(torch.stack(cv), torch.stack(ci), k)
+    assert torch.equal(mv, v_ref) and torch.equal(mi, i_ref), "8 shards + merge differ from the unsharded top-k"
+    compare_sample(v_ref, i_ref, feature, bank_rows, k, "fp32", n_sample=64)
+
+
+def test_c1_cifar100_full_size_fp32_bit_exact_on_sampled_rows(ica):
+    """BASELINE configs[0] at full size (10 000 queries x 50 000 x 128 bank, C = 100) through the reference's [D, N]
+    layout, fp32: 256 sampled query rows are recomputed by the CHAIN ORACLE (oracle/knn_chain.c) against the whole
+    bank -- values and indices bit-equal, vote scores within 1e-5 relative, top-1 equal where the scores decide it."""
+    B, N, D, C, k, T = 10_000, 50_000, 128, 100, 200, 0.1
+    bank_rows = unit_rows(N, D, 8)
+    feature = unit_rows(B, D, 9)
+    labels = torch.randint(0, C, (N,), generator=torch.Generator(device="cuda").manual_seed(10), device="cuda")
+    out = ica.knn_predict_full(feature, bank_rows.t().contiguous(), labels, C, k, T, compute_dtype="fp32")
+    check_rows_wellformed(out["sim_weight"], out["sim_indices"], N)
+    assert tuple(out["pred_labels"].shape) == (B, C)
+    rows = np.sort(np.random.RandomState(1).choice(B, 256, replace=False))
+    ref = ko.knn_from_similarity(chain.sim_chain_f32(feature[rows].cpu().numpy(), bank_rows.cpu().numpy()),
+                                 labels.cpu().numpy(), C, k, T)
+    got = {n: v[torch.from_numpy(rows).cuda()].cpu().numpy() for n, v in out.items()}
+    assert np.array_equal(got["sim_weight"], ref["sim_weight"]), "C1: similarities differ from the chain oracle"
+    assert np.array_equal(got["sim_indices"], ref["sim_indices"]), "C1: top-k indices differ from the chain oracle"
+    P.check_scores(got["pred_scores"], ref["pred_scores"], "C1")
+    P.check_ranking_prefix(got["pred_labels"], got["pred_scores"], "C1")
+    assert P.check_top1(got["pred_labels"], ref["pred_labels"], ref["pred_scores"], "C1") > 200
+
+
+def test_c1_cifar100_full_size_bf16_vs_bf16_oracle(ica):
+    """The same configuration in the throughput mode against the bf16 oracle (exact products of the bf16-rounded
+    inputs, float64 accumulation) on 128 sampled rows: values within 4*D*eps, index sets equal where the k-th gap
+    exceeds twice that (tests/parity.py contract)."""
+    B, N, D, C, k, T = 10_000, 50_000, 128, 100, 200, 0.1
+    bank_rows = unit_rows(N, D, 8)
+    feature = unit_rows(B, D, 9)
+    labels = torch.randint(0, C, (N,), generator=torch.Generator(device="cuda").manual_seed(10), device="cuda")
+    out = ica.knn_predict_full(feature, bank_rows.t().contiguous(), labels, C, k, T, compute_dtype="bf16")
+    check_rows_wellformed(out["sim_weight"], out["sim_indices"], N)
+    rows = np.sort(np.random.RandomState(2).choice(B, 128, replace=False))
+    sim = chain.sim_bf16_f64(ko.to_bf16_bits(feature[rows].cpu().numpy()), ko.to_bf16_bits(bank_rows.cpu().numpy()))
+    ref = ko.knn_from_similarity(sim, labels.cpu().numpy(), C, k, T)
+    srt = -np.sort(-sim, axis=1)
+    gap = srt[:, k - 1] - srt[:, k]
+    got = {n: v[torch.from_numpy(rows).cuda()].cpu().numpy() for n, v in out.items()}
+    n = P.check_topk(got["sim_weight"], got["sim_indices"], ref["sim_weight"], ref["sim_indices"], gap, D, False, "C1 bf16")
+    assert n >= 16, f"only {n} sampled rows had a decided k-th boundary"
+    decided = P.decided_rows(gap, D)
+    rtol = 1e-5 + P.val_atol(D) / T
+    P.check_scores(got["pred_scores"], ref["pred_scores"], "C1 bf16", rtol=rtol, rows=decided)
+    P.check_top1(got["pred_labels"], ref["pred_labels"], ref["pred_scores"], "C1 bf16", rtol=rtol, rows=decided)

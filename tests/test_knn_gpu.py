@@ -155,6 +155,36 @@ def test_all_ties_pick_lowest_indices(ica):
         assert np.all(v.cpu().numpy() == np.float32(D * 0.125 * 0.25))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_unwritten_query_rows_of_the_storage_bank(ica, dtype):
+    """``StorageBank.register`` fills ``test_feature`` with +inf (memory_bank.py:16-18) and ``knn_test`` hands the
+    whole buffer to ``knn_predict`` (ssltrainer.py:184): a row no ``test_step`` has written is all +inf.  Its
+    similarities are inf * x summed over mixed signs = NaN.  The reference then returns an ARBITRARY ranking for it
+    (torch.topk orders NaN first, exp(NaN) = NaN, and 0 * NaN = NaN poisons every class of the one-hot product,
+    knn.py:18; argsort of an all-NaN row is unspecified).  The rule here (mi_knn.h, mi_knn_topk): NaN similarities are
+    never selected, the row is padded with (-inf, -1), receives no vote and ranks the classes in ascending order --
+    and the written rows that share its 256-row tile are not touched by it."""
+    f, x, lab = _rand_case(300, 6000, 64, 7, 31)
+    bad = [0, 5, 255, 256, 299]
+    f_inf = f.copy()
+    f_inf[bad] = np.inf
+    C, k, T = 7, 200, 0.1
+    good = np.setdiff1d(np.arange(300), bad)
+    ref = run_full(ica, f, x, lab, C, k, T, dtype)
+    out = run_full(ica, f_inf, x, lab, C, k, T, dtype)
+    for n in ref:
+        assert np.array_equal(out[n][good], ref[n][good]), f"{n}: a written row changed because a neighbour row is +inf"
+    assert np.all(np.isneginf(out["sim_weight"][bad])) and np.all(out["sim_indices"][bad] == -1)
+    assert np.all(out["pred_scores"][bad] == 0) and np.array_equal(out["pred_labels"][bad], np.tile(np.arange(C), (len(bad), 1)))
+    # what torch does with the same row, for the record in DESIGN.md: all-NaN similarities and all-NaN scores
+    sim = torch.from_numpy(f_inf[:1]) @ torch.from_numpy(x.T.copy())
+    assert bool(torch.isnan(sim).all())
+    # a +inf row against a same-signed bank is +inf, not NaN: selected like any other value (lower rows first)
+    xp = np.abs(x)
+    v, i = ica.knn_topk(dev(f_inf[:1]), ica.BankIndex.from_rows(dev(xp), dtype), 5)
+    assert np.all(np.isposinf(v.cpu().numpy())) and i.cpu().numpy().tolist() == [[0, 1, 2, 3, 4]]
+
+
 def test_k_larger_than_n_raises_like_torch(ica):
     f, x, _ = _rand_case(4, 10, 32, 3, 0)
     with pytest.raises(RuntimeError, match="out of range"):
