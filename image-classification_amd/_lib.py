@@ -75,7 +75,7 @@ def lib() -> ctypes.CDLL:
     L.mi_moco_fwd.restype = i32
     L.mi_moco_fwd.argtypes = [p, p, p, i64, i64, i64, f32, p, p, p, p, sz, p]
     L.mi_moco_bwd.restype = i32
-    L.mi_moco_bwd.argtypes = [p, p, p, i64, i64, i64, f32, p, p, p, p, p, i64, i64, p, sz, p]
+    L.mi_moco_bwd.argtypes = [p, p, p, i64, i64, i64, f32, p, p, p, p, p, p, i64, i64, p, sz, p]
     L.mi_queue_push_stash.restype = i32
     L.mi_queue_push_stash.argtypes = [p, i64, i64, i64, p, i64, p, ctypes.POINTER(i64), p]
     if L.mi_abi_version() != ABI_VERSION:

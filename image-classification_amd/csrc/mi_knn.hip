@@ -228,7 +228,8 @@ __global__ void push_kernel(char *__restrict__ dst, const char *__restrict__ src
     }
 }
 
-// wrapping ring-buffer enqueue (models/module_utils.py:73-85): item row r -> queue row (cursor + r) % K
+// wrapping ring-buffer enqueue (models/module_utils.py:73-85): item row r -> queue row (cursor + r) % K; when the
+// batch is longer than the queue (b <= 2K - cursor) the rows both slice assignments write keep the later item row
 __global__ void push_wrap_kernel(char *__restrict__ queue, long long K, long long row_bytes, long long cursor,
                                  const char *__restrict__ value, long long b, int vec)
 {
@@ -238,7 +239,8 @@ __global__ void push_wrap_kernel(char *__restrict__ queue, long long K, long lon
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long long r = i / per, c = i - r * per;
         long long dst = cursor + r;
-        if (dst >= K) dst -= K;
+        if (dst >= K) dst -= K;                       // second slice assignment: data[:left] = item[right:]
+        else if (dst < b - (K - cursor)) continue;    // b > K: the second assignment rewrites this row (later item rows win)
         if (vec) ((uint4 *)(queue + dst * row_bytes))[c] = ((const uint4 *)(value + r * row_bytes))[c];
         else queue[dst * row_bytes + c] = value[r * row_bytes + c];
     }
@@ -358,7 +360,7 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     // (+ one bit per (tile, row) in the tile masks: B_pad / 2048; rounded up into the 1024-byte slack)
     const int64_t row_bytes = (int64_t)pl.B_pad * 8 + pl.B_pad / 128 + (pl.B_pad + 2047) / 2048;
     int64_t cap = ((cand_bytes < 0 ? CAND_BUDGET_BYTES : cand_bytes) - 1024 - 4 * pl.B_pad) / row_bytes / STAGE_QUANTUM * STAGE_QUANTUM;
-    int64_t useful = round_up(N > S0_COLS ? N - S0_COLS : S0_COLS, STAGE_QUANTUM);        // one stage for all the rest
+    int64_t useful = round_up(N > S0_COLS ? N : S0_COLS, STAGE_QUANTUM);        // one stage for the whole bank
     if (useful < S0_COLS) useful = S0_COLS;
     if (cap > useful) cap = useful;
     // Keep one stage's bank slice (+ the query chunk) resident in the 256 MiB Infinity Cache: the
@@ -400,7 +402,7 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
 #ifndef MI_LATE_GROWTH_DIV
 #define MI_LATE_GROWTH_DIV 4
 #endif
-int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t N)
+int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t left)      // left: bank rows not filtered yet
 {
     int64_t n = 3 * seen / STAGE_QUANTUM * STAGE_QUANTUM;
     if (n < pl.min_cols) n = pl.min_cols;
@@ -409,7 +411,7 @@ int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t N)
         if (n < pl.launch_cols) n = pl.launch_cols;
     }
     if (n > pl.cap) n = pl.cap;
-    if (n > N - seen) n = N - seen;
+    if (n > left) n = left;
     return n;
 }
 
@@ -615,17 +617,25 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
     sel.k = k;
     sel.idx_base = idx_base;
 
-    // stage 0: dense bootstrap over the first s0 bank rows
+    // stage 0: dense bootstrap.  A bank no larger than the bootstrap is finished by it.  Otherwise the bootstrap
+    // runs over a STRIDED SAMPLE of the bank (every floor(N / s0)-th row: whatever order the bank is in -- an
+    // ImageFolder memo loader hands it over class by class, ssltrainer.py:226-230 -- the sample sees every part
+    // of it) and only its k-th largest value is kept: a lower bound of the row's final k-th similarity, i.e. a
+    // valid first threshold.  Its keys are dropped, so every bank row, the sampled ones included, passes through
+    // the filter exactly once and the kept keys stay distinct.
+    const bool sampled = N > pl.s0_cols;
     sp.col0 = 0;
     sp.ncols = pl.s0_cols;
     sp.ntiles = (int)ceil_div(pl.s0_cols, mi::TILE);
+    sp.row_stride = sampled ? (int)(N / pl.s0_cols) : 1;
     {
         ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * sp.ncols * (double)D, s);
         HIP_CHECK((launch_sim_dt<mi::MODE_DENSE>(dtype, sp, s)));
     }
-    int64_t col = pl.s0_cols;
+    int64_t col = sampled ? 0 : pl.s0_cols;          // bank rows filtered (or finished) so far
     sel.dense_n = pl.s0_cols;
     sel.dense_col0 = 0;
+    sel.tau_only = sampled ? 1 : 0;
     if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
     {
         ProfScope ps(MI_PROF_SELECT, (double)B * sel.dense_n * 4.0, s);
@@ -640,7 +650,7 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
     sel.big_stride = big_stride(pl.B_pad);
     for (int stage = 0; col < N; ++stage) {
         sel.parity = stage & 1;
-        const int64_t ncols = next_stage_cols(pl, col, N);
+        const int64_t ncols = next_stage_cols(pl, col + (sampled ? pl.s0_cols : 0), N - col);   // the sample counts as "seen"
         sel.ntiles = (int)ceil_div(ncols, mi::TILE);
         for (int64_t off = 0; off < ncols; off += pl.launch_cols) {          // launch_cols is a whole number of tiles
             const int64_t lc = ncols - off < pl.launch_cols ? ncols - off : pl.launch_cols;
@@ -802,7 +812,7 @@ int mi_queue_push_wrap(void *queue, int64_t K, int64_t row_bytes, int64_t cursor
 {
     if (!queue || !value) return fail(MI_ERR_ARG, "mi_queue_push_wrap: null pointer");
     if (K < 1 || row_bytes < 1 || b < 0 || cursor < 0 || cursor >= K) return fail(MI_ERR_ARG, "mi_queue_push_wrap: bad shape K=%lld row_bytes=%lld b=%lld cursor=%lld", (long long)K, (long long)row_bytes, (long long)b, (long long)cursor);
-    if (b > K) return fail(MI_ERR_ARG, "mi_queue_push_wrap: shape mismatch: %lld rows do not fit a queue of %lld (the reference's second slice assignment fails the same way)", (long long)b, (long long)K);
+    if (b - (K - cursor) > K) return fail(MI_ERR_ARG, "mi_queue_push_wrap: shape mismatch: %lld rows from cursor %lld do not fit a queue of %lld (the reference's second slice assignment, data[:left] = item[right:] with left > K, fails the same way)", (long long)b, (long long)cursor, (long long)K);
     if (b > 0) {
         const int vec = ((((uintptr_t)queue | (uintptr_t)value) & 15) == 0 && (row_bytes & 15) == 0) ? 1 : 0;
         const long long items = b * (vec ? row_bytes >> 4 : row_bytes);
@@ -903,35 +913,40 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
 
 int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
                 int64_t D, float temperature, const float *lse, const float *lpos,
-                const float *grad_loss, float *dq,
+                const float *grad_loss, float *dq, float *dkey,
                 const float *patch_rows, int64_t patch_lo, int64_t patch_n,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream)
 {
-    if (!q || !key || !queue || !lse || !lpos || !grad_loss || !dq || !workspace) return fail(MI_ERR_ARG, "mi_moco_bwd: null pointer");
+    if (!q || !key || !lse || !lpos || !grad_loss) return fail(MI_ERR_ARG, "mi_moco_bwd: null pointer");
+    if (!dq && !dkey) return fail(MI_ERR_ARG, "mi_moco_bwd: dq and dkey are both null");
     if (b < 1 || K < 1 || D < 1 || b > (1 << 24) || K > INT32_MAX - 2 * mi::TILE) return fail(MI_ERR_ARG, "mi_moco_bwd: bad shape");
-    if (D % 64 || D > 256) return fail(MI_ERR_UNSUPPORTED, "mi_moco_bwd: D=%lld must be a multiple of 64 and at most 256", (long long)D);
     if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_moco_bwd: temperature must be positive");
-    if (patch_n < 0 || patch_lo < 0 || patch_lo + patch_n > K || (patch_n > 0 && !patch_rows)) return fail(MI_ERR_ARG, "mi_moco_bwd: bad patch range [%lld, +%lld) for K=%lld", (long long)patch_lo, (long long)patch_n, (long long)K);
-    if (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)workspace | (uintptr_t)patch_rows | (uintptr_t)dq) & 15) return fail(MI_ERR_ARG, "mi_moco_bwd: q, queue, patch_rows, dq, workspace must be 16-byte aligned");
-    const MocoPlan mp = moco_plan(b, K, D);
-    if (workspace_bytes < mp.bwd_total) return fail(MI_ERR_WORKSPACE, "mi_moco_bwd: workspace %zu < required %zu", workspace_bytes, mp.bwd_total);
     hipStream_t s = (hipStream_t)stream;
-    mi::AttendParams bp{};
-    bp.q = q;
-    bp.bank = queue;
-    bp.lse = lse;
-    bp.patch = patch_n > 0 ? patch_rows : nullptr;
-    bp.patch_lo = (int)patch_lo;
-    bp.patch_n = (int)patch_n;
-    bp.b = (int)b;
-    bp.K = (int)K;
-    bp.inv_t = 1.0f / temperature;
-    bp.part = (float *)workspace;
-    bp.rows_per_slice = mp.rows_per_slice;
-    const dim3 grid((unsigned)ceil_div(b, mi::MB_ROWS), (unsigned)mp.nslices);
-    const size_t lds = mi::attend_lds_bytes((int)D, (int)D, false);
-    {
-        ProfScope ps(MI_PROF_MOCO_BWD, 4.0 * (double)b * (double)K * (double)D, s);
+    const float inv_t = 1.0f / temperature;
+    int nslices = 0;
+    ProfScope ps(MI_PROF_MOCO_BWD, (dq ? 4.0 * (double)b * (double)K * (double)D : 0.0), s);
+    if (dq) {
+        if (!queue || !workspace) return fail(MI_ERR_ARG, "mi_moco_bwd: null pointer");
+        if (D % 64 || D > 256) return fail(MI_ERR_UNSUPPORTED, "mi_moco_bwd: D=%lld must be a multiple of 64 and at most 256", (long long)D);
+        if (patch_n < 0 || patch_lo < 0 || patch_lo + patch_n > K || (patch_n > 0 && !patch_rows)) return fail(MI_ERR_ARG, "mi_moco_bwd: bad patch range [%lld, +%lld) for K=%lld", (long long)patch_lo, (long long)patch_n, (long long)K);
+        if (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)workspace | (uintptr_t)patch_rows | (uintptr_t)dq) & 15) return fail(MI_ERR_ARG, "mi_moco_bwd: q, queue, patch_rows, dq, workspace must be 16-byte aligned");
+        const MocoPlan mp = moco_plan(b, K, D);
+        if (workspace_bytes < mp.bwd_total) return fail(MI_ERR_WORKSPACE, "mi_moco_bwd: workspace %zu < required %zu", workspace_bytes, mp.bwd_total);
+        mi::AttendParams bp{};
+        bp.q = q;
+        bp.bank = queue;
+        bp.lse = lse;
+        bp.patch = patch_n > 0 ? patch_rows : nullptr;
+        bp.patch_lo = (int)patch_lo;
+        bp.patch_n = (int)patch_n;
+        bp.b = (int)b;
+        bp.K = (int)K;
+        bp.inv_t = inv_t;
+        bp.part = (float *)workspace;
+        bp.rows_per_slice = mp.rows_per_slice;
+        nslices = mp.nslices;
+        const dim3 grid((unsigned)ceil_div(b, mi::MB_ROWS), (unsigned)mp.nslices);
+        const size_t lds = mi::attend_lds_bytes((int)D, (int)D, false);
 #define MI_LAUNCH_BWD(D64)                                                                                       \
         do {                                                                                                    \
             HIP_CHECK(hipFuncSetAttribute((const void *)mi::attend_kernel<D64, D64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -945,10 +960,10 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
         }
 #undef MI_LAUNCH_BWD
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(mi::moco_bwd_reduce_kernel, dim3((unsigned)ceil_div(b * D, 256)), dim3(256), 0, s,
-                           (const float *)workspace, mp.nslices, (int)b, (int)D, key, lse, lpos, grad_loss, bp.inv_t, dq);
-        HIP_CHECK(hipGetLastError());
     }
+    hipLaunchKernelGGL(mi::moco_bwd_reduce_kernel, dim3((unsigned)ceil_div(b * D, 256)), dim3(256), 0, s,
+                       (const float *)workspace, nslices, (int)b, (int)D, q, key, lse, lpos, grad_loss, inv_t, dq, dkey);
+    HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
 

@@ -195,18 +195,25 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
     }
 }
 
-// dq[i][d] = g * inv_t / b * ( sum_s part[s][i][d] + (exp(lpos_i * inv_t - lse_i) - 1) * key[i][d] )
+// dq[i][d]   = g * inv_t / b * ( sum_s part[s][i][d] + (p_pos_i - 1) * key[i][d] )      p_pos_i = exp(lpos_i * inv_t - lse_i)
+// dkey[i][d] = g * inv_t / b * (p_pos_i - 1) * q[i][d]            (the positive logit q_i . key_i is the only term with key)
+// Either output may be null (dq == nullptr: `part` is not read).
 __global__ __launch_bounds__(256) void moco_bwd_reduce_kernel(const float *part, int nslices, int b, int D,
-                                                              const float *key, const float *lse, const float *lpos,
-                                                              const float *grad_loss, float inv_t, float *dq)
+                                                              const float *q, const float *key, const float *lse,
+                                                              const float *lpos, const float *grad_loss, float inv_t,
+                                                              float *dq, float *dkey)
 {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)b * D) return;
     const int row = (int)(e / D);
-    float s = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) s += part[(long long)sl * b * D + e];
     const float ppos = __expf(lpos[row] * inv_t - lse[row]);
-    dq[e] = grad_loss[0] * inv_t / (float)b * (s + (ppos - 1.f) * key[e]);
+    const float scale = grad_loss[0] * inv_t / (float)b;
+    if (dq) {
+        float s = 0.f;
+        for (int sl = 0; sl < nslices; ++sl) s += part[(long long)sl * b * D + e];
+        dq[e] = scale * (s + (ppos - 1.f) * key[e]);
+    }
+    if (dkey) dkey[e] = scale * (ppos - 1.f) * q[e];
 }
 
 // probs_out[i][c] = alpha * probs_in[i][c] + (1 - alpha) * (sum_s part[s][i][c]) / (sum_s part[s][i][C])

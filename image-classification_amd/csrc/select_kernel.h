@@ -77,6 +77,8 @@ struct SelectParams {
     float *out_val;             // [B, k]
     long long *out_idx;         // [B, k]
     long long idx_base;
+    int tau_only;               // SRC_DENSE: the dense values are a SAMPLE of the bank -- only the threshold is kept
+                                // (topk_n stays 0: every bank row, the sampled ones included, goes through the filter once)
     int skip_small;             // SRC_LIST: rows with <= MERGE_MAX_NEW candidates were merged by merge_kernel
     // SRC_LIST work list: merge_kernel appends the rows it leaves to select_kernel (> MERGE_MAX_NEW
     // candidates) to big_rows and counts them in big_cnt[parity]; select_kernel<SRC_LIST> then runs a
@@ -302,10 +304,13 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
         for (int i = tid; i < p.mask_words; i += SEL_THREADS) p.tmask[(long long)row * p.mask_words + i] = 0u;
     }
     if constexpr (SRC != SRC_GATHER) {
-        for (int i = tid; i < n_cur; i += SEL_THREADS) p.topk[(long long)row * p.k + i] = keys[i];
+        const bool keep = !(SRC == SRC_DENSE && p.tau_only);
+        if (keep)
+            for (int i = tid; i < n_cur; i += SEL_THREADS) p.topk[(long long)row * p.k + i] = keys[i];
         if (tid == 0) {
-            p.topk_n[row] = n_cur;
-            p.tau[row] = (n_cur >= p.k) ? key_value(keys[p.k - 1]) : -INFINITY;
+            p.topk_n[row] = keep ? n_cur : 0;
+            // tau only ever rises: it stays at its initial -inf (or at the sample's threshold) until k keys are held
+            if (n_cur >= p.k) p.tau[row] = key_value(keys[p.k - 1]);
         }
     }
     if (finalize) {
@@ -596,10 +601,13 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
     if constexpr (SRC == SRC_LIST) {
         for (int i = lane; i < p.mask_words; i += 64) p.tmask[row * p.mask_words + i] = 0u;
     }
-    for (int i = lane; i < n_cur; i += 64) p.topk[row * p.k + i] = keys[i];
+    const bool keep = !(SRC == SRC_DENSE && p.tau_only);
+    if (keep)
+        for (int i = lane; i < n_cur; i += 64) p.topk[row * p.k + i] = keys[i];
     if (lane == 0) {
-        p.topk_n[row] = n_cur;
-        p.tau[row] = (n_cur >= p.k) ? key_value(keys[p.k - 1]) : -INFINITY;
+        p.topk_n[row] = keep ? n_cur : 0;
+        // tau only ever rises: it stays at its initial -inf (or at the sample's threshold) until k keys are held
+        if (n_cur >= p.k) p.tau[row] = key_value(keys[p.k - 1]);
     }
     if (finalize) {
         for (int i = lane; i < p.k; i += 64) {
@@ -753,6 +761,254 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
         for (int i = n_out + lane; i < k; i += 64) {
             p.out_val[row * k + i] = -INFINITY;
             p.out_idx[row * k + i] = -1ll;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident threshold refresh (k <= 256): ONE wave folds ONE query row's new candidates into
+// the row's kept keys and raises its threshold -- the stage refresh of the filter scheme.
+//
+// The kept keys are a BAG (unsorted, compact: slots [0, topk_n) of the row): between stages only the
+// threshold matters, the order is needed once, at the end.  A refresh is therefore a SELECTION, not a
+// sort, and it runs in registers:
+//   * the row's candidates are located by a per-tile exclusive prefix of the stage's counts (cnt2, through
+//     the row's tile bitmask) in a wave-private LDS window, candidate j finds its (tile, slot) by binary
+//     search, and every lane loads its candidates straight into registers -- all loads of a batch are in
+//     flight together (the lists are short and scattered: latency, not bandwidth, is the cost);
+//   * the k-th largest of kept + new keys comes from an MSB-first BINARY radix select on wave ballots: one
+//     ballot + popcount per register slot and key bit, only over the bits in which the keys differ at all,
+//     stopping when one key is left (about log2(keys) + a few steps); no LDS histogram, no atomics, no barrier;
+//   * the survivors (exactly k: keys are distinct) are compacted through 2 KiB of wave-private LDS back into
+//     the bag; the final stage sorts that LDS copy (bitonic, wave-private) and emits (value, index).
+// This replaces the counting merge + LDS radix-select/compact/sort pair for k <= 256 (per stage of 16 384 rows:
+// ~140 us -> see DESIGN.md); k > 256 keeps the workgroup-per-row kernels above.
+constexpr int BAG_WIN = 1024;          // bank tiles per prefix window (4 KiB of LDS per wave)
+constexpr int BAG_TPL = BAG_WIN / 64;  // consecutive tiles per lane
+constexpr int BAG_NSLOT = 12;          // new candidates per lane and batch (768 per batch)
+
+struct BagSmem {
+    unsigned pre[BAG_WIN];             // exclusive prefix of the window's per-tile candidate counts
+    unsigned long long bag[256];       // survivors of a batch, compacted; sorted in place by the final stage
+};
+
+// rank-th largest (1-based) of the non-zero keys held in registers by one wave: pk[KPL] (kept) and nk[ns] (new).
+// Needs nz >= rank >= 1 non-zero keys, all distinct.  Every lane returns the same key.
+template <int KPL>
+__device__ __forceinline__ unsigned long long bag_select_kth(const unsigned long long (&pk)[KPL],
+                                                             const unsigned long long (&nk)[BAG_NSLOT], int ns,
+                                                             int nz, int rank)
+{
+    unsigned long long a = ~0ull, o = 0ull;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+        if (pk[j]) { a &= pk[j]; o |= pk[j]; }
+#pragma unroll
+    for (int s2 = 0; s2 < BAG_NSLOT; ++s2)
+        if (s2 < ns && nk[s2]) { a &= nk[s2]; o |= nk[s2]; }
+    a = wave_and64(a);
+    o = wave_or64(o);
+    const unsigned long long var = a ^ o;                       // bits in which the keys differ at all
+    if (var == 0ull) return a;                                  // one key
+    unsigned act = 0u;                                          // bit j: pk[j] still a candidate; bit KPL + s: nk[s]
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) act |= (pk[j] != 0ull) ? (1u << j) : 0u;
+#pragma unroll
+    for (int s2 = 0; s2 < BAG_NSLOT; ++s2) act |= (s2 < ns && nk[s2] != 0ull) ? (1u << (KPL + s2)) : 0u;
+    int r = rank, n_act = nz;
+    for (int bit = 63 - __clzll((long long)var); bit >= 0; --bit) {
+        if (!((var >> bit) & 1ull)) continue;                   // every key agrees on this bit (wave-uniform)
+        const bool hiw = bit >= 32;
+        const unsigned msk = 1u << (bit & 31);
+        unsigned ones = 0u;                                     // slots that are active AND have the bit set
+        int cnt1 = 0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const unsigned w = hiw ? (unsigned)(pk[j] >> 32) : (unsigned)pk[j];
+            const bool m = ((act >> j) & 1u) && (w & msk);
+            cnt1 += __popcll(__ballot(m));
+            ones |= m ? (1u << j) : 0u;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
+            if (s2 < ns) {                                      // wave-uniform
+                const unsigned w = hiw ? (unsigned)(nk[s2] >> 32) : (unsigned)nk[s2];
+                const bool m = ((act >> (KPL + s2)) & 1u) && (w & msk);
+                cnt1 += __popcll(__ballot(m));
+                ones |= m ? (1u << (KPL + s2)) : 0u;
+            }
+        }
+        if (cnt1 >= r) { act = ones; n_act = cnt1; }            // the rank-th largest has this bit set
+        else { r -= cnt1; act &= ~ones; n_act -= cnt1; }
+        if (n_act <= 1) break;
+    }
+    unsigned long long found = 0ull;                            // the one key left (distinct keys)
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+        if ((act >> j) & 1u) found = pk[j];
+#pragma unroll
+    for (int s2 = 0; s2 < BAG_NSLOT; ++s2)
+        if (s2 < ns && ((act >> (KPL + s2)) & 1u)) found = nk[s2];
+    return wave_or64(found);
+}
+
+template <int KPL>
+__global__ __launch_bounds__(256) void bag_refresh_kernel(const SelectParams p)
+{
+    __shared__ BagSmem smem[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wv;
+    if (row >= p.B) return;
+    BagSmem &sm = smem[wv];
+    const bool finalize = p.out_val != nullptr;
+    const int k = p.k;
+    unsigned *tm = p.tmask + row * p.mask_words;
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+
+    unsigned long long pk[KPL];
+    bool have_pk = false, any = false;
+    int n_cur = 0;
+    unsigned long long kth_last = 0ull;
+    auto load_bag = [&]() {                                     // deferred: rows without candidates never read it
+        n_cur = p.topk_n[row];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) pk[j] = (j * 64 + lane) < n_cur ? p.topk[row * k + j * 64 + lane] : 0ull;
+        have_pk = true;
+    };
+
+    for (int w0 = 0; w0 < p.ntiles; w0 += BAG_WIN) {
+        // this lane's BAG_TPL consecutive tiles of the window: one 16-bit piece of the row's tile mask
+        const int t0 = w0 + lane * BAG_TPL;
+        unsigned bits = 0u;
+        if (t0 < p.ntiles) bits = (tm[t0 >> 5] >> (t0 & 31)) & 0xFFFFu;
+        if (__ballot(bits != 0u) == 0ull) continue;             // no candidate of this row in the window
+        int cnt[BAG_TPL];
+        int mine = 0;
+#pragma unroll
+        for (int i = 0; i < BAG_TPL; ++i) {
+            int c = 0;
+            if ((bits >> i) & 1u) c = (int)p.cnt2[(long long)(t0 + i) * p.bpad + row];     // t0 + i < ntiles: the bit is set
+            cnt[i] = c;
+            mine += c;
+        }
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o2 = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o2;
+        }
+        const int cw = __shfl(incl, 63, 64);                    // candidates of the row in this window
+        if (cw == 0) continue;
+        {
+            unsigned run = (unsigned)(incl - mine);
+#pragma unroll
+            for (int i = 0; i < BAG_TPL; ++i) {
+                sm.pre[lane * BAG_TPL + i] = run;
+                run += (unsigned)cnt[i];
+            }
+        }
+        wave_step();
+        if (!have_pk) load_bag();
+        for (int j0 = 0; j0 < cw; j0 += BAG_NSLOT * 64) {
+            const int nb = (cw - j0) < BAG_NSLOT * 64 ? (cw - j0) : BAG_NSLOT * 64;
+            const int ns = (nb + 63) >> 6;
+            // candidate j -> (tile = largest tau with pre[tau] <= j, slot j - pre[tau]); all loads issued together
+            unsigned long long nk[BAG_NSLOT];
+            uint2 cd[BAG_NSLOT];
+            int pos[BAG_NSLOT];
+#pragma unroll
+            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) pos[s2] = 0;
+#pragma unroll
+            for (int step = BAG_WIN / 2; step > 0; step >>= 1) {
+#pragma unroll
+                for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
+                    if (s2 < ns) {
+                        const unsigned j = (unsigned)(j0 + s2 * 64 + lane);
+                        if (sm.pre[pos[s2] + step] <= j) pos[s2] += step;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
+                cd[s2] = make_uint2(0x7FC00000u, 0u);                                   // NaN: key 0 (empty)
+                if (s2 < ns) {
+                    const int j = j0 + s2 * 64 + lane;
+                    if (j < j0 + nb) {
+                        const int e = j - (int)sm.pre[pos[s2]];
+                        cd[s2] = p.cand[row * p.cap + (long long)(w0 + pos[s2]) * 256 + e];
+                    }
+                }
+            }
+            int nz = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
+                nk[s2] = 0ull;
+                if (s2 < ns) {
+                    nk[s2] = make_key(__uint_as_float(cd[s2].x), cd[s2].y);
+                    nz += __popcll(__ballot(nk[s2] != 0ull));
+                }
+            }
+            nz += n_cur;
+            const int keep = nz < k ? nz : k;
+            unsigned long long kth = 1ull;                      // fewer than k keys: keep every real one
+            if (nz >= k) { kth = bag_select_kth<KPL>(pk, nk, ns, nz, k); kth_last = kth; }
+            // survivors -> compact LDS bag (exactly `keep`: keys are distinct; `< k` guards the LDS block regardless)
+            wave_step();
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const bool take = pk[j] >= kth && pk[j] != 0ull;
+                const unsigned long long bal = __ballot(take);
+                const int at = base + __popcll(bal & ltmask);
+                if (take && at < k) sm.bag[at] = pk[j];
+                base += __popcll(bal);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
+                if (s2 < ns) {
+                    const bool take = nk[s2] >= kth && nk[s2] != 0ull;
+                    const unsigned long long bal = __ballot(take);
+                    const int at = base + __popcll(bal & ltmask);
+                    if (take && at < k) sm.bag[at] = nk[s2];
+                    base += __popcll(bal);
+                }
+            }
+            wave_step();
+            n_cur = keep;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) pk[j] = (j * 64 + lane) < n_cur ? sm.bag[j * 64 + lane] : 0ull;
+            any = true;
+        }
+        wave_step();                                            // sm.pre is rewritten by the next window
+    }
+
+    if (any) {
+        for (int i = lane; i < p.mask_words; i += 64) tm[i] = 0u;           // consumed: the next stage starts clear
+        if (!finalize) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j)
+                if ((j * 64 + lane) < n_cur) p.topk[row * k + j * 64 + lane] = pk[j];
+            if (lane == 0) {
+                p.topk_n[row] = n_cur;
+                if (kth_last) p.tau[row] = key_value(kth_last);             // tau only ever rises
+            }
+        }
+    }
+    if (finalize) {
+        if (!have_pk) load_bag();
+        int n2 = 64;
+        while (n2 < n_cur) n2 <<= 1;
+        wave_step();
+#pragma unroll
+        for (int j = 0; j < KPL; ++j)
+            if (j * 64 < n2) sm.bag[j * 64 + lane] = pk[j];                 // zeros pad up to n2
+        wave_step();
+        wave_bitonic_sort_desc(sm.bag, n2, lane);
+        for (int i = lane; i < k; i += 64) {
+            const bool ok = i < n_cur;
+            const unsigned long long key = ok ? sm.bag[i] : 0ull;
+            p.out_val[row * k + i] = ok ? key_value(key) : -INFINITY;
+            p.out_idx[row * k + i] = ok ? p.idx_base + (long long)key_row(key) : -1ll;
         }
     }
 }

@@ -4,7 +4,9 @@
 //     sim[b][n] = sum_k q[b][k] * bank[n][k]                       (models/knn.py:6)
 // with MFMA and never writes it to HBM.  What leaves the tile depends on MODE:
 //   MODE_DENSE  : bootstrap stage -- the tile is stored densely (values only) into the per-row
-//                 candidate buffer, the select kernel turns it into the first top-k + threshold;
+//                 candidate buffer, the select kernel turns it into the first threshold (a strided
+//                 sample of the bank: dense column c = bank row c * row_stride) or, for a bank no
+//                 larger than the bootstrap, into the final top-k;
 //   MODE_FILTER : every element is compared with its row's threshold tau[row] (a lower bound of
 //                 the row's final k-th largest similarity); survivors (rare) go straight to the
 //                 (row, bank tile) segment of the row's candidate buffer in HBM -- slot from an LDS
@@ -54,6 +56,7 @@ struct SimParams {
     int ksteps;               // padded row bytes / 128
     int col0, ncols;          // this launch covers bank rows [col0, col0 + ncols)
     int nt_base;              // MODE_FILTER: stage tile of the launch's tile 0 (a stage may take several launches)
+    int row_stride;           // MODE_DENSE: dense column c is bank row c * row_stride (strided sample of the bank)
     int qtiles, ntiles;       // tiles in this launch
     int pq, pn, qsh;          // patches of (1 << qsh) query tiles x (32 >> qsh) bank tiles (set by the launcher)
     // MODE_DENSE / MODE_FILTER
@@ -140,7 +143,12 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         const int r = (w * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         int qa = q0 + r; qa = qa < p.B ? qa : p.B - 1;             // clamp: padding rows re-read a valid row
-        int xb = n0 + r; xb = xb < p.N ? xb : p.N - 1;
+        int xb = n0 + r;
+        if constexpr (MODE == MODE_DENSE) {                          // padding columns re-read the last sampled row
+            xb = xb < col_end ? xb : col_end - 1;
+            xb *= p.row_stride;                                      // < N: (s0 - 1) * floor(N / s0)
+        }
+        xb = xb < p.N ? xb : p.N - 1;
 #if defined(MI_ABLATE) && (MI_ABLATE & 1)
         xb = r;                                                      // timing-only: bank tile 0 for everyone
 #endif
@@ -220,7 +228,12 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             int r = q0 + la * (inner >> p.qsh) + idx; r = r < p.B ? r : p.B - 1;
             pf_src = p.q + (long long)r * p.ldq_bytes;
         } else {
-            int r = n0 + lb * (inner & ((1 << p.qsh) - 1)) + (idx - la); r = r < p.N ? r : p.N - 1;
+            int r = n0 + lb * (inner & ((1 << p.qsh) - 1)) + (idx - la);
+            if constexpr (MODE == MODE_DENSE) {
+                r = r < col_end ? r : col_end - 1;
+                r *= p.row_stride;
+            }
+            r = r < p.N ? r : p.N - 1;
             pf_src = p.x + (long long)r * p.ldx_bytes;
         }
     }

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_topk_static", "knn_vote", "knn_merge", "BankIndex", "BankBuilder",
+__all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_topk_static", "knn_vote", "knn_merge", "check_labels", "BankIndex", "BankBuilder",
            "pack_rows", "DEFAULT_COMPUTE_DTYPE"]
 
 # "fp32": exact float32 products, one k-ascending fma chain per similarity (the parity mode);
@@ -244,15 +244,32 @@ def knn_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor, k: int) -> Tuple[t
     return val, idx
 
 
+def check_labels(feature_labels: torch.Tensor, classes: int) -> None:
+    """The reference raises (index error in ``scatter``, ``models/knn.py:16``) when a bank label is outside
+    ``[0, classes)``; the vote kernel would silently give such a neighbour no vote.  One fused min/max over the labels
+    and one host read; skipped while the stream is being captured into a HIP graph (no host read is possible there)."""
+    if feature_labels.numel() == 0 or (feature_labels.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return
+    lo, hi = (int(v) for v in torch.aminmax(feature_labels))
+    if lo < 0 or hi >= int(classes):
+        raise IndexError(f"feature_labels span [{lo}, {hi}] but classes={int(classes)}: every label must lie in "
+                         f"[0, classes) (models/knn.py:16 raises here too)")
+
+
 def knn_vote(sim_weight: torch.Tensor, sim_indices: torch.Tensor, feature_labels: torch.Tensor,
-             classes: int, knn_t: float, return_scores: bool = False):
-    """Label gather, exp(s/T) weights, class vote, ranking (``models/knn.py:10-20``)."""
+             classes: int, knn_t: float, return_scores: bool = False, check: bool = True):
+    """Label gather, exp(s/T) weights, class vote, ranking (``models/knn.py:10-20``).
+
+    ``sim_indices`` address ``feature_labels`` (entries < 0 are padding and get no vote); ``check`` validates the
+    label range first (:func:`check_labels`), as the reference's ``scatter`` would."""
     _require_device(sim_weight, "sim_weight")
     dev = sim_weight.device
     B, k = sim_weight.shape
     labels = feature_labels.to(device=dev, dtype=torch.int64).contiguous()
     if labels.dim() != 1:
         raise ValueError("feature_labels must be 1-D")
+    if check:
+        check_labels(labels, classes)
     sim_weight = sim_weight.contiguous()
     sim_indices = sim_indices.contiguous()
     rank = torch.empty((B, int(classes)), dtype=torch.int64, device=dev)

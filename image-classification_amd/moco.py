@@ -8,7 +8,8 @@ from the repository: parity unpinned).  The call site fixes the co
                             query_neg=False, key_neg=False, temperature=0.1, norm=False)
 
 ``query`` [b, D] requires grad, ``key`` [b, D] and ``memory`` [K, D] are detached; only the queue
-supplies negatives.  MoCo semantics: ``l_pos = q.k``, ``l_neg = q @ memory^T``,
+supplies negatives.  The symmetric branch (``moco.py:138-149``) also calls it with ``query=feat_key`` (no grad) and
+``key=feat_query`` (requires grad): the gradient w.r.t. ``key`` is returned as well.  MoCo semantics: ``l_pos = q.k``, ``l_neg = q @ memory^T``,
 ``loss = mean CE([l_pos, l_neg] / T, target 0)``.
 
 :func:`contrastive_loss2` keeps those keyword names for that subset.  The [b, K+1] logits are never
@@ -98,6 +99,11 @@ class _MocoQueueLoss(torch.autograd.Function):
         b, D = q.shape
         K = memory.shape[0]
         dev = q.device
+        need_dq, need_dkey = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_dq and (D % 64 or D > 256):
+            # fail HERE, not from inside autograd in the middle of a train step: the fused backward w.r.t. the query
+            # (mi_moco_bwd) is built for D % 64 == 0, D <= 256 (the reference's feature_dim is 128)
+            raise NotImplementedError(f"the backward w.r.t. query needs D % 64 == 0 and D <= 256, got D={D}")
         ws_bytes = int(L.mi_moco_workspace_bytes(b, K, D))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         lse = torch.empty(b, dtype=torch.float32, device=dev)
@@ -109,50 +115,66 @@ class _MocoQueueLoss(torch.autograd.Function):
                                      _lib.stream_ptr(dev)), "mi_moco_fwd")
         ctx.save_for_backward(q, k, lse, lpos)
         ctx.temperature = float(temperature)
-        ctx.ws = ws
-        pend = _Pending(memory)
-        ctx.pending = pend
-        _PENDING.setdefault(memory.data_ptr(), []).append(weakref.ref(pend))
+        ctx.ws = ws if need_dq else None
+        ctx.pending = None
+        if need_dq:
+            # only the query gradient reads the queue again: pushes must protect its rows until backward has run
+            pend = _Pending(memory)
+            ctx.pending = pend
+            _PENDING.setdefault(memory.data_ptr(), []).append(weakref.ref(pend))
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_loss):
         q, k, lse, lpos = ctx.saved_tensors
-        pend: _Pending = ctx.pending
+        need_dq, need_dkey = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        pend: Optional[_Pending] = ctx.pending
         L = _lib.lib()
         b, D = q.shape
-        memory = pend.snapshot if pend.snapshot is not None else pend.memory
-        K = memory.shape[0]
         dev = q.device
         g = grad_loss.detach().reshape(1).float().contiguous()
-        dq = torch.empty_like(q)
-        patch = pend.patch_rows
+        dq = torch.empty_like(q) if need_dq else None
+        dkey = torch.empty_like(k) if need_dkey else None
+        memory = patch = None
+        K = 1
+        if need_dq:
+            memory = pend.snapshot if pend.snapshot is not None else pend.memory
+            K = memory.shape[0]
+            patch = pend.patch_rows
         with torch.cuda.device(dev):
-            _lib.check(L.mi_moco_bwd(q.data_ptr(), k.data_ptr(), memory.data_ptr(), b, K, D, ctx.temperature,
-                                     lse.data_ptr(), lpos.data_ptr(), g.data_ptr(), dq.data_ptr(),
+            _lib.check(L.mi_moco_bwd(q.data_ptr(), k.data_ptr(), memory.data_ptr() if need_dq else None, b, K, D,
+                                     ctx.temperature, lse.data_ptr(), lpos.data_ptr(), g.data_ptr(),
+                                     dq.data_ptr() if need_dq else None, dkey.data_ptr() if need_dkey else None,
                                      patch.data_ptr() if patch is not None else None,
                                      pend.patch_lo if patch is not None else 0,
                                      patch.shape[0] if patch is not None else 0,
-                                     ctx.ws.data_ptr(), ctx.ws.numel(), _lib.stream_ptr(dev)), "mi_moco_bwd")
-        # backward has run: pushes no longer need to protect rows for this loss
-        refs = _PENDING.get(pend.memory.data_ptr())
-        if refs:
-            refs[:] = [r for r in refs if r() is not None and r() is not pend]
-            if not refs:
-                _PENDING.pop(pend.memory.data_ptr(), None)
-        ctx.pending = None
-        return dq, None, None, None
+                                     ctx.ws.data_ptr() if need_dq else None, ctx.ws.numel() if need_dq else 0,
+                                     _lib.stream_ptr(dev)), "mi_moco_bwd")
+        if pend is not None:
+            # backward has run: pushes no longer need to protect rows for this loss
+            refs = _PENDING.get(pend.memory.data_ptr())
+            if refs:
+                refs[:] = [r for r in refs if r() is not None and r() is not pend]
+                if not refs:
+                    _PENDING.pop(pend.memory.data_ptr(), None)
+            ctx.pending = None
+        return dq, dkey, None, None
 
 
 def moco_queue_loss(query: torch.Tensor, key: torch.Tensor, memory: torch.Tensor, temperature: float = 0.1) -> torch.Tensor:
     """InfoNCE of ``query`` against its positive ``key`` and the negative queue ``memory`` (scalar).
 
-    Differentiable w.r.t. ``query`` only (``key`` / ``memory`` are detached at the call site)."""
+    Differentiable w.r.t. ``query`` (the default call site, ``moco.py:152-156``) and w.r.t. ``key`` (the symmetric
+    branch passes ``key=feat_query``, ``moco.py:144-148``).  The queue holds detached features in every call site
+    of the reference; a ``memory`` that requires grad raises instead of silently dropping that gradient."""
     for name, t in (("query", query), ("key", key), ("memory", memory)):
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
             raise RuntimeError(f"{name} must be a tensor on an MI355X (HIP) device: image-classification_amd has no CPU fallback")
     if query.dim() != 2 or key.shape != query.shape or memory.dim() != 2 or memory.shape[1] != query.shape[1]:
         raise ValueError(f"expected query/key [b, D] and memory [K, D], got {tuple(query.shape)}, {tuple(key.shape)}, {tuple(memory.shape)}")
+    if memory.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("no gradient w.r.t. the negative queue is built: pass memory.detach() "
+                                  "(every call site of the reference holds detached features in the queue)")
     return _MocoQueueLoss.apply(query, key, memory.detach(), float(temperature))
 
 

@@ -63,8 +63,10 @@ class _WrappingQueue(torch.Tensor):
             if not data.is_contiguous():
                 raise RuntimeError("queue storage must be contiguous")
             item = item.detach().to(device=data.device, dtype=data.dtype).contiguous()
-            if len(item) > self.queue_size:
-                raise RuntimeError(f"shape mismatch: cannot push {len(item)} rows into a queue of {self.queue_size}")
+            if len(item) - (self.queue_size - self.cursor) > self.queue_size:
+                # the reference's `self.data[:left] = item[right:]` raises here (module_utils.py:82) -- after its
+                # first slice assignment has already been written; this push raises before writing anything
+                raise RuntimeError(f"shape mismatch: cannot push {len(item)} rows at cursor {self.cursor} into a queue of {self.queue_size}")
             row_bytes = data.element_size() * (data[0].numel() if data.dim() > 1 else 1)
             new_cursor = ctypes.c_int64(0)
             with torch.cuda.device(data.device):

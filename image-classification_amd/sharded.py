@@ -73,7 +73,40 @@ class HipOps:
         return self._knn.knn_merge(cand_val, cand_idx, k)
 
     def vote(self, val, idx, labels, classes, knn_t):
-        return self._knn.knn_vote(val, idx, labels, classes, knn_t)
+        return self._knn.knn_vote(val, idx, labels, classes, knn_t, check=False)      # validated once per predict()
+
+    def check_labels(self, labels, classes):
+        self._knn.check_labels(labels, classes)
+
+
+# -- collectives: ONE call site each, whatever the backend ------------------------------------
+def _on_device(group) -> bool:
+    """RCCL (backend "nccl") moves device tensors itself; any other backend (gloo in the CPU tests and in the
+    two-ranks-on-one-GPU test) gets the SAME collective call with the SAME split sizes on host copies."""
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_to_all(group, recv: torch.Tensor, send: torch.Tensor, out_splits, in_splits):
+    """recv <- all_to_all_single(send); returns the pending work (None once complete)."""
+    if _on_device(group):
+        return dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                      group=group, async_op=True)
+    hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+    dist.all_to_all_single(hrecv, send.cpu().contiguous(), output_split_sizes=out_splits,
+                           input_split_sizes=in_splits, group=group)
+    recv.copy_(hrecv)
+    return None
+
+
+def _all_gather(group, out: torch.Tensor, mine: torch.Tensor, async_op: bool = False):
+    """out [G * n, ...] <- all_gather_into_tensor(mine [n, ...]); returns the pending work (None once complete)."""
+    if _on_device(group):
+        w = dist.all_gather_into_tensor(out, mine.contiguous(), group=group, async_op=async_op)
+        return w if async_op else None
+    hout = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_gather_into_tensor(hout, mine.cpu().contiguous(), group=group)
+    out.copy_(hout)
+    return None
 
 
 class ShardedKnn:
@@ -107,6 +140,35 @@ class ShardedKnn:
         self.n_total = sum(sizes)
 
     # -- one exchange step ------------------------------------------------------------------
+    # -- one exchange step ------------------------------------------------------------------
+    # -- collectives: ONE call site each, whatever the backend --------------------------------
+    def _on_device(self) -> bool:
+        """RCCL (backend "nccl") moves device tensors itself; any other backend (gloo in the CPU tests and in the
+        two-ranks-on-one-GPU test) gets the SAME collective call with the SAME split sizes on host copies."""
+        return dist.get_backend(self.group) == "nccl"
+
+    def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, out_splits, in_splits):
+        """recv <- all_to_all_single(send); returns the pending work (None once complete)."""
+        if self._on_device():
+            return dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                          group=self.group, async_op=True)
+        hrecv = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(hrecv, send.cpu().contiguous(), output_split_sizes=out_splits,
+                               input_split_sizes=in_splits, group=self.group)
+        recv.copy_(hrecv)
+        return None
+
+    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor, async_op: bool = False):
+        """out [G * n, ...] <- all_gather_into_tensor(mine [n, ...]); returns the pending work (None once complete)."""
+        if self._on_device():
+            w = dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group, async_op=async_op)
+            return w if async_op else None
+        hout = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(hout, mine.cpu().contiguous(), group=self.group)
+        out.copy_(hout)
+        return None
+
+    # -- one exchange step ------------------------------------------------------------------
     def _exchange(self, val: torch.Tensor, idx: torch.Tensor):
         """all-gather [B, k] candidates -> [G, B, k]; returns (gathered_val, gathered_idx, works)."""
         if self.solo:
@@ -114,19 +176,9 @@ class ShardedKnn:
         G = self.world
         gv = torch.empty((G,) + tuple(val.shape), dtype=val.dtype, device=val.device)
         gi = torch.empty((G,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-        if dist.get_backend(self.group) == "nccl":
-            w1 = dist.all_gather_into_tensor(gv, val.contiguous(), group=self.group, async_op=True)
-            w2 = dist.all_gather_into_tensor(gi, idx.contiguous(), group=self.group, async_op=True)
-            return gv, gi, (w1, w2)
-        # any other backend (gloo in the tests): synchronous, staged through host memory
-        hv, hi = val.cpu().contiguous(), idx.cpu().contiguous()
-        lv = [torch.empty_like(hv) for _ in range(G)]
-        li = [torch.empty_like(hi) for _ in range(G)]
-        dist.all_gather(lv, hv, group=self.group)
-        dist.all_gather(li, hi, group=self.group)
-        gv.copy_(torch.stack(lv))
-        gi.copy_(torch.stack(li))
-        return gv, gi, ()
+        w1 = _all_gather(self.group, gv.view((G * val.shape[0],) + tuple(val.shape[1:])), val, async_op=True)
+        w2 = _all_gather(self.group, gi.view((G * idx.shape[0],) + tuple(idx.shape[1:])), idx, async_op=True)
+        return gv, gi, tuple(w for w in (w1, w2) if w is not None)
 
     def _local_candidates(self, f: torch.Tensor, k: int):
         """Local top-k padded to k columns with (-inf, -1) when this shard holds fewer than k rows."""
@@ -146,6 +198,8 @@ class ShardedKnn:
         launch tails, exchange and merge of one chunk run beside the next chunk's GEMM."""
         if k > self.n_total:
             raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
+        if self.n_total >= 2 ** 32:
+            raise ValueError("mi_knn_merge keys global rows as 32-bit values: N must be < 2^32")
         B = feature.shape[0]
         starts = chunk_bounds(B, self.query_chunk)
         side = _side_streams(feature.device, self.n_streams) if (feature.is_cuda and len(starts) > 1) else None
@@ -196,17 +250,12 @@ class ShardedKnn:
             return (val, idx), None                      # one rank, no exchange: the candidates are the result
         lo, hi = shard_bounds(c, G, self.rank)
         send = torch.stack((val.contiguous().view(torch.int32), idx.to(torch.int32)), dim=1)        # [c, 2, k]
-        if dist.get_backend(self.group) == "nccl":
-            sizes = [shard_bounds(c, G, j)[1] - shard_bounds(c, G, j)[0] for j in range(G)]
-            recv = torch.empty((G * (hi - lo), 2, k), dtype=torch.int32, device=val.device)
-            work = dist.all_to_all_single(recv, send, output_split_sizes=[hi - lo] * G, input_split_sizes=sizes,
-                                          group=self.group, async_op=True)
-            return recv.view(G, hi - lo, 2, k), work
-        # any other backend (gloo in the tests): all-gather through host memory, keep the own slice
-        host = send.cpu().contiguous()
-        parts = [torch.empty_like(host) for _ in range(G)]
-        dist.all_gather(parts, host, group=self.group)
-        return torch.stack([p[lo:hi] for p in parts]).to(val.device), None
+        # rows of `send` that go to rank j = rank j's slice of the chunk; every rank sends me MY slice's rows
+        in_splits = [shard_bounds(c, G, j)[1] - shard_bounds(c, G, j)[0] for j in range(G)]
+        out_splits = [hi - lo] * G
+        recv = torch.empty((G * (hi - lo), 2, k), dtype=torch.int32, device=val.device)
+        work = _all_to_all(self.group, recv, send, out_splits, in_splits)
+        return recv.view(G, hi - lo, 2, k), work
 
     def _own_slice(self, pending, k, feature_labels, classes, knn_t):
         buf, work = pending
@@ -241,6 +290,8 @@ class ShardedKnn:
             raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
         if self.n_total >= 2 ** 31:
             raise ValueError("the candidate exchange carries int32 global rows: N must be < 2^31")
+        if hasattr(self.ops, "check_labels"):
+            self.ops.check_labels(feature_labels, classes)
         B, G = feature.shape[0], self.world
         starts = chunk_bounds(B, self.query_chunk)
         slices, rows = [None] * len(starts), []
@@ -285,14 +336,9 @@ class ShardedKnn:
         longest = max(sum(hi - lo for lo, hi in (pc[j] for pc in per_chunk)) for j in range(G))
         padded = torch.zeros((longest, width), dtype=torch.int64, device=mine.device)
         padded[:mine.shape[0]] = mine
-        if dist.get_backend(self.group) == "nccl":
-            allr = torch.empty((G * longest, width), dtype=torch.int64, device=mine.device)
-            dist.all_gather_into_tensor(allr, padded, group=self.group)
-            allr = allr.view(G, longest, width)
-        else:
-            parts = [torch.empty_like(padded.cpu()) for _ in range(G)]
-            dist.all_gather(parts, padded.cpu(), group=self.group)
-            allr = torch.stack(parts).to(mine.device)
+        allr = torch.empty((G * longest, width), dtype=torch.int64, device=mine.device)
+        _all_gather(self.group, allr, padded)
+        allr = allr.view(G, longest, width)
         out = torch.empty((B, width), dtype=torch.int64, device=mine.device)
         offs = [0] * G
         for (s, _), pc in zip(starts, per_chunk):
@@ -324,6 +370,8 @@ class QuerySlicedKnn:
         k, classes, knn_t = int(knn_k), int(classes), float(knn_t)
         if k > self.n_total:
             raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
+        if hasattr(self.ops, "check_labels"):
+            self.ops.check_labels(feature_labels, classes)
         B, G = feature.shape[0], self.world
         lo, hi = shard_bounds(B, G, self.rank)
         parts = []
@@ -341,14 +389,9 @@ class QuerySlicedKnn:
         longest = shard_bounds(B, G, 0)[1]                          # rank 0 holds the longest slice
         padded = torch.zeros((longest, width), dtype=torch.int64, device=mine.device)
         padded[:mine.shape[0]] = mine
-        if dist.get_backend(self.group) == "nccl":
-            allr = torch.empty((G * longest, width), dtype=torch.int64, device=mine.device)
-            dist.all_gather_into_tensor(allr, padded, group=self.group)
-            allr = allr.view(G, longest, width)
-        else:
-            got = [torch.empty_like(padded.cpu()) for _ in range(G)]
-            dist.all_gather(got, padded.cpu(), group=self.group)
-            allr = torch.stack(got).to(mine.device)
+        allr = torch.empty((G * longest, width), dtype=torch.int64, device=mine.device)
+        _all_gather(self.group, allr, padded)
+        allr = allr.view(G, longest, width)
         out = torch.cat([allr[j, :shard_bounds(B, G, j)[1] - shard_bounds(B, G, j)[0]] for j in range(G)], 0)
         return out if gather == "full" else out[:, 0].contiguous()
 

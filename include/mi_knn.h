@@ -141,8 +141,10 @@ int mi_queue_push(void *queue, int64_t K, int64_t row_bytes, int64_t ptr,
 /* WRAPPING ring-buffer enqueue.  Replaces models/module_utils.py:73-85 (MemoryBank.push and
  * LongTensorMemoryBank.push:125-136, the queues of supcontrast/ft/infomin/cmc/swav/byol): value row r goes
  * to queue row (cursor + r) % K -- the overflow wraps to the front instead of being dropped -- and the new
- * cursor (cursor + b) % K is stored to *new_cursor (HOST pointer, may be NULL).  b > K is an error, as in the
- * reference (its second slice assignment cannot fit). */
+ * cursor (cursor + b) % K is stored to *new_cursor (HOST pointer, may be NULL).  A batch longer than the queue is
+ * accepted exactly where the reference's two slice assignments fit (b <= 2K - cursor: `data[cursor:] = item[:right]`,
+ * then `data[:left] = item[right:]` -- rows written by both keep the later item row); b > 2K - cursor is an error, as
+ * the reference's second assignment raises (it has written the first slice by then; this call writes nothing). */
 int mi_queue_push_wrap(void *queue, int64_t K, int64_t row_bytes, int64_t cursor,
                        const void *value, int64_t b, int64_t *new_cursor, mi_stream_t stream);
 
@@ -164,18 +166,22 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
                 int64_t D, float temperature, float *lse, float *lpos, float *loss,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
-/* Backward w.r.t. the query only (key and queue are detached at the call site, moco.py:153-154):
- *   dq[i] = grad_loss / (b T) * ( sum_n softmax_i[n] queue[n] + (softmax_i[pos] - 1) key_i )
+/* Backward.  At the reference's default call site key and queue are detached (moco.py:152-154) and only dq is
+ * wanted; its symmetric branch (moco.py:144-148, `query=feat_key, key=feat_query`) carries the gradient through
+ * `key` instead.  Either output may be NULL (not both):
+ *   dq[i]   = grad_loss / (b T) * ( sum_n softmax_i[n] queue[n] + (softmax_i[pos] - 1) key_i )
+ *   dkey[i] = grad_loss / (b T) * (softmax_i[pos] - 1) q_i          (needs only lse / lpos: no pass over the queue)
  * The probabilities are recomputed tile by tile from q, queue and lse (never stored).
- * grad_loss: device pointer to the upstream scalar gradient.  D % 64 == 0, D <= 256.
+ * grad_loss: device pointer to the upstream scalar gradient.  dq needs D % 64 == 0, D <= 256 and the workspace
+ * (mi_moco_workspace_bytes covers forward and backward); with dq == NULL queue/workspace may be NULL and any D
+ * the forward accepts is fine.
  * The reference pushes into the queue BEFORE backward (moco.py:159-172) and therefore clones the
  * whole queue every step (moco.py:153).  Here the caller may pass the live, already pushed-into
  * queue plus the rows the push overwrote: queue rows [patch_lo, patch_lo + patch_n) are read from
- * patch_rows [patch_n, D] instead (patch_n == 0: no patch, patch_rows may be NULL).
- * Workspace: mi_moco_workspace_bytes (covers forward and backward). */
+ * patch_rows [patch_n, D] instead (patch_n == 0: no patch, patch_rows may be NULL). */
 int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b, int64_t K,
                 int64_t D, float temperature, const float *lse, const float *lpos,
-                const float *grad_loss, float *dq,
+                const float *grad_loss, float *dq, float *dkey,
                 const float *patch_rows, int64_t patch_lo, int64_t patch_n,
                 void *workspace, size_t workspace_bytes, mi_stream_t stream);
 

@@ -282,15 +282,16 @@ def moco_queue_init(K: int, D: int, rng=None) -> np.ndarray:
     return l2_normalize(rng.rand(K, D).astype(F32))
 
 
-def moco_loss(query, key, memory, temperature, dtype=np.float64):
+def moco_loss(query, key, memory, temperature, dtype=np.float64, with_dkey=False):
     """InfoNCE of the MoCo paper as the call site moco.py:152-156 specifies it
     (query_neg=False, key_neg=False, norm=False): PARITY UNPINNED (lumo absent).
 
       l_pos[i] = q_i . k_i ; l_neg = q @ memory^T ; logits = [l_pos, l_neg] / T
       loss = mean_i ( logsumexp(logits_i) - logits_i[0] )
 
-    Returns (loss, dloss/dquery, lse[b], l_pos[b]); gradients w.r.t. key/memory are not part
-    of the path (both detached at the call site)."""
+    Returns (loss, dloss/dquery, lse[b], l_pos[b]) -- plus dloss/dkey with ``with_dkey`` (the symmetric
+    branch moco.py:144-148 passes ``key=feat_query``; only the positive logit depends on the key).  The
+    gradient w.r.t. memory is not part of the path (the queue holds detached features)."""
     q = np.asarray(query, dtype)
     kk = np.asarray(key, dtype)
     m = np.asarray(memory, dtype)
@@ -305,4 +306,6 @@ def moco_loss(query, key, memory, temperature, dtype=np.float64):
     p[:, 0] -= 1.0
     p /= (b * temperature)
     dq = p[:, :1] * kk + p[:, 1:] @ m
+    if with_dkey:
+        return loss, dq, lse, l_pos, p[:, :1] * q
     return loss, dq, lse, l_pos

@@ -244,6 +244,13 @@ def wrapping_queue_cases():
     except RuntimeError:
         too_big = "RuntimeError"
     out["oversized_push"] = np.array([too_big])
+    # batch longer than the queue but within 2K - cursor: both slice assignments fit, the rows written twice keep
+    # the later item rows (K = 10, cursor 5, 12 rows: data[5:] = item[:5], data[:7] = item[5:], cursor 7)
+    mb = MemoryBank(queue_size=10, feature_dim=2)
+    mb.push(torch.full((5, 2), 500.0))
+    mb.push((torch.arange(12, dtype=torch.float32) + 1000.0)[:, None].expand(12, 2).contiguous())
+    out["overlong_k10_c5_b12_final"] = mb.tensor().numpy().copy()
+    out["overlong_k10_c5_b12_cursor"] = np.array([mb.cursor], np.int64)
     c = MemoryBank(queue_size=6, feature_dim=2)
     c.push(torch.ones(4, 2))
     out["attrs_survive"] = np.array([c.clone().cursor, c.to(torch.float64).cursor, c.clone().queue_size], np.int64)

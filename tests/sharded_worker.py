@@ -71,8 +71,21 @@ def main(rank, world, port, use_gpu, out_dir):
         qpred = qs.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T)
         qtop1 = qs.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T, gather="top1")
         assert torch.equal(qpred, pred) and torch.equal(qtop1, top1)
+        # uneven chunks: 50 queries in chunks of 7 leave a last chunk of 8 (the 1-row tail is folded in), and with
+        # query_chunk=1 every chunk is ONE query, so all ranks but one own a zero-row slice of it -- the split sizes
+        # of the all_to_all_single and the interleave undo of the final gather see 0-row pieces
+        small = {"local_rows": knn.local_rows.cpu().numpy()}
+        for qc, nq in ((7, 50), (1, 5)):
+            knn.query_chunk = qc
+            fq = torch.from_numpy(f[:nq]).to(dev)
+            small[f"pred_qc{qc}"] = knn.predict(fq, torch.from_numpy(lab).to(dev), C, k, T).cpu().numpy()
+            small[f"top1_qc{qc}"] = knn.predict(fq, torch.from_numpy(lab).to(dev), C, k, T, gather="top1").cpu().numpy()
+            small[f"rows_qc{qc}"] = knn.local_rows.cpu().numpy()
+            v2, i2 = knn.topk(fq, k)
+            # (CPU stand-in ops: MKL's summation order moves with the chunk shape, so values get a tolerance there)
+            assert torch.equal(i2, idx[:nq]) and (torch.equal(v2, val[:nq]) if use_gpu else torch.allclose(v2, val[:nq], atol=1e-6))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), val=val.cpu().numpy(), idx=idx.cpu().numpy(),
-                 pred=pred.cpu().numpy(), top1=top1.cpu().numpy(), local_rows=knn.local_rows.cpu().numpy())
+                 pred=pred.cpu().numpy(), top1=top1.cpu().numpy(), **small)
         # MemoryBank.push all-gathers the keys of every rank first (memory_bank.py:64)
         if use_gpu:
             mb = ica.MemoryBank()

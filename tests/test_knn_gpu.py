@@ -263,6 +263,22 @@ def test_vote_skips_padding_entries(ica):
     assert rank.cpu().numpy()[0].tolist() == [1, 0, 2]
 
 
+def test_labels_outside_the_class_range_raise_like_the_reference(ica):
+    """models/knn.py:16 (`scatter` of the one-hot) raises for a label >= classes; the HIP vote would silently drop the
+    neighbour, so the host checks the range first -- in knn_predict, knn_vote and the sharded predict."""
+    f, x, lab = _rand_case(9, 500, 32, 5, 4)
+    bad = lab.copy()
+    bad[7] = 5
+    with pytest.raises(IndexError, match="classes=5"):
+        ica.knn_predict(dev(f), dev(x.T.copy()), dev(bad), 5, 20, 0.1)
+    bad[7] = -1
+    with pytest.raises(IndexError):
+        ica.knn_predict(dev(f), dev(x.T.copy()), dev(bad), 5, 20, 0.1)
+    with pytest.raises(IndexError):
+        ica.sharded.ShardedKnn(dev(x), 0, compute_dtype="fp32").predict(dev(f), dev(bad), 5, 20, 0.1)
+    assert tuple(ica.knn_predict(dev(f), dev(x.T.copy()), dev(lab), 5, 20, 0.1).shape) == (9, 5)
+
+
 def test_deterministic_across_runs(ica):
     f, x, lab = _rand_case(257, 20000, 128, 100, 11)
     a = ica.knn_predict_full(dev(f), dev(x.T.copy()), dev(lab), 100, 200, 0.1, compute_dtype="bf16")

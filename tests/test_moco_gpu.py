@@ -118,6 +118,52 @@ def test_push_before_backward_uses_pre_push_queue(ica, ptr0, pushes):
     assert torch.equal(tq.grad, tq_ref.grad)                                        # same kernel, same inputs: bitwise
 
 
+def test_symmetric_branch_carries_the_key_gradient(ica):
+    """moco.py:138-149 (params.symmetric): Lcsa = loss(query=feat_query, key=feat_key) and
+    Lcsb = loss(query=feat_key, key=feat_query) -- feat_key comes out of a no_grad block, so Lcsb's whole
+    gradient flows through ``key``.  d(Lcsa + Lcsb)/d feat_query against the float64 oracle and torch autograd."""
+    b, K, D, T = 96, 3000, 128, 0.1
+    q, k, mem = make(b, K, D, 41)
+    _, dq_a, _, _ = ko.moco_loss(q, k, mem, T)
+    loss_b, _, _, _, dkey_b = ko.moco_loss(k, q, mem, T, with_dkey=True)
+    tq = torch.from_numpy(q).cuda().requires_grad_(True)
+    tk, tm = torch.from_numpy(k).cuda(), torch.from_numpy(mem).cuda()
+    la = ica.contrastive_loss2(query=tq, key=tk, memory=tm, query_neg=False, key_neg=False, temperature=T, norm=False)
+    lb = ica.contrastive_loss2(query=tk, key=tq, memory=tm, query_neg=False, key_neg=False, temperature=T, norm=False)
+    assert abs(lb.item() - loss_b) <= LOSS_RTOL * abs(loss_b)
+    (la + lb).backward()
+    ref = dq_a + dkey_b
+    assert np.max(np.abs(tq.grad.cpu().numpy() - ref)) <= DQ_RTOL * np.max(np.abs(ref))
+    # the same sum from torch autograd on the device
+    tq2 = torch.from_numpy(q).cuda().requires_grad_(True)
+
+    def torch_loss(qq, kk):
+        logits = torch.cat([(qq * kk).sum(1, keepdim=True), qq @ tm.t()], 1) / T
+        return F.cross_entropy(logits, torch.zeros(b, dtype=torch.long, device="cuda"))
+    (torch_loss(tq2, tk) + torch_loss(tk, tq2)).backward()
+    g = tq2.grad.cpu().numpy()
+    assert np.max(np.abs(tq.grad.cpu().numpy() - g)) <= DQ_RTOL * np.max(np.abs(g))
+    # key-only gradient needs no pass over the queue and therefore not the query backward's D limits
+    q3, k3, mem3 = make(20, 500, 96, 43)
+    t3 = torch.from_numpy(q3).cuda().requires_grad_(True)
+    ica.contrastive_loss2(query=torch.from_numpy(k3).cuda(), key=t3, memory=torch.from_numpy(mem3).cuda(), temperature=T).backward()
+    dkey3 = ko.moco_loss(k3, q3, mem3, T, with_dkey=True)[4]
+    assert np.max(np.abs(t3.grad.cpu().numpy() - dkey3)) <= DQ_RTOL * np.max(np.abs(dkey3))
+
+
+def test_gradients_that_are_not_built_fail_at_the_forward(ica):
+    """A queue that requires grad, and a query gradient at a feature_dim the fused backward is not built for, raise
+    when the loss is CALLED -- not from inside autograd in the middle of a train step, and never silently."""
+    q, k, mem = make(8, 64, 96, 2)
+    tq, tk, tm = torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(mem).cuda()
+    with pytest.raises(NotImplementedError, match="negative queue"):
+        ica.contrastive_loss2(query=tq, key=tk, memory=tm.clone().requires_grad_(True))
+    with pytest.raises(NotImplementedError, match="D % 64"):
+        ica.contrastive_loss2(query=tq.clone().requires_grad_(True), key=tk, memory=tm)
+    loss = ica.contrastive_loss2(query=tq, key=tk, memory=tm)                    # no gradient asked: D = 96 is fine
+    assert abs(loss.item() - ko.moco_loss(q, k, mem, 0.1)[0]) <= LOSS_RTOL * abs(loss.item())
+
+
 def test_deterministic(ica):
     q, k, mem = make(200, 30000, 128, 5)
     a = run(ica, q, k, mem, 0.1)

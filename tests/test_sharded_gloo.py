@@ -2,6 +2,8 @@
 
 CPU leg: gloo + oracle-backed compute ops (the HIP kernels cannot run here) -- checks the shard
 bounds, global indices, chunked exchange, merge and vote wiring against the single-process oracle.
+The exchange goes through the SAME ``all_to_all_single`` / ``all_gather_into_tensor`` calls, with the same
+split sizes, as the RCCL path (``ShardedKnn._all_to_all`` / ``_all_gather``); only the staging differs.
 GPU leg (-m gpu): the same flow with the real HIP ops, two ranks sharing the box's one GPU."""
 import os
 import socket
@@ -55,6 +57,15 @@ def _check(outs, ref, exact_values):
         assert np.array_equal(o["top1"], o["pred"][:, 0])
     owned = np.sort(np.concatenate([o["local_rows"] for o in outs]))
     assert np.array_equal(owned, np.arange(outs[0]["pred"].shape[0]))   # every query has exactly one owner
+    # uneven chunkings (7-row chunks with a folded tail; 1-row chunks = zero-row slices on all ranks but one):
+    # the same rankings as the 16-row chunking above, on every rank
+    for qc, nq in ((7, 50), (1, 5)):
+        for o in outs:
+            assert np.array_equal(o[f"pred_qc{qc}"], outs[0]["pred"][:nq]), f"query_chunk={qc}"
+            assert np.array_equal(o[f"top1_qc{qc}"], outs[0]["pred"][:nq, 0])
+        owned = np.sort(np.concatenate([o[f"rows_qc{qc}"] for o in outs]))
+        assert np.array_equal(owned, np.arange(nq))
+    assert any(o["rows_qc1"].size == 0 or o["rows_qc1"].size < 5 for o in outs)
 
 
 def test_shard_bounds_cover_everything():

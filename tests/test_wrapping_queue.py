@@ -44,6 +44,11 @@ def test_oracle_long_queue_and_oversized_push():
     assert z["oversized_push"][0] == "RuntimeError"
     with pytest.raises(RuntimeError):
         ko.WrappingQueueOracle(5, 2).push(np.zeros((12, 2), np.float32))
+    # longer than the queue but within 2K - cursor: the reference's two slice assignments both fit
+    q = ko.WrappingQueueOracle(10, 2)
+    q.push(np.full((5, 2), 500.0, np.float32))
+    q.push(np.repeat((np.arange(12, dtype=np.float32) + 1000.0)[:, None], 2, axis=1))
+    assert np.array_equal(q.data, z["overlong_k10_c5_b12_final"]) and q.cursor == int(z["overlong_k10_c5_b12_cursor"][0])
 
 
 def test_attributes_survive_like_the_reference():
@@ -97,7 +102,21 @@ def test_hip_long_queue_random_rows_and_errors():
         orc.push(v)
         assert q.cursor == orc.cursor
     assert np.array_equal(q.tensor().cpu().numpy(), orc.data)           # bitwise row copies
+    assert q.cursor == 24
     with pytest.raises(RuntimeError, match="shape mismatch"):
-        q.push(torch.zeros(1001, 128).cuda())
+        q.push(torch.zeros(1977, 128).cuda())                           # left = 1977 - 976 = 1001 > K, as the reference
+    # longer than the queue, within 2K - cursor: the reference's recorded result (rows written twice keep the later row)
+    q = ica.module_utils.MemoryBank(10, 2).to("cuda")
+    q.push(torch.full((5, 2), 500.0).cuda())
+    q.push((torch.arange(12, dtype=torch.float32) + 1000.0)[:, None].expand(12, 2).contiguous().cuda())
+    assert np.array_equal(q.tensor().cpu().numpy(), z["overlong_k10_c5_b12_final"]) and q.cursor == int(z["overlong_k10_c5_b12_cursor"][0])
+    v = rs.randn(1900, 128).astype(np.float32)                          # and at size: 1900 rows into 1000 from cursor 24
+    q = ica.module_utils.MemoryBank(1000, 128).to("cuda")
+    orc = ko.WrappingQueueOracle(1000, 128)
+    orc.data = q.tensor().cpu().numpy().copy()
+    for item in (v[:24], v):
+        q.push(torch.from_numpy(item).cuda())
+        orc.push(item)
+    assert q.cursor == orc.cursor == (24 + 1900) % 1000 and np.array_equal(q.tensor().cpu().numpy(), orc.data)
     with pytest.raises(AssertionError):
         q.push(torch.zeros(4, 64).cuda())

@@ -24,7 +24,7 @@ st = _lib.stream_ptr(dev)
 def fwd():
     _lib.check(L.mi_moco_fwd(q.data_ptr(), k.data_ptr(), mem.data_ptr(), b, K, D, T, lse.data_ptr(), lpos.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws_bytes, st), "fwd")
 def bwd():
-    _lib.check(L.mi_moco_bwd(q.data_ptr(), k.data_ptr(), mem.data_ptr(), b, K, D, T, lse.data_ptr(), lpos.data_ptr(), g.data_ptr(), dq.data_ptr(), None, 0, 0, ws.data_ptr(), ws_bytes, st), "bwd")
+    _lib.check(L.mi_moco_bwd(q.data_ptr(), k.data_ptr(), mem.data_ptr(), b, K, D, T, lse.data_ptr(), lpos.data_ptr(), g.data_ptr(), dq.data_ptr(), None, None, 0, 0, ws.data_ptr(), ws_bytes, st), "bwd")
 
 for name, fn in (("fwd", fwd), ("bwd", bwd)):
     for _ in range(20):
