@@ -635,11 +635,11 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
     int64_t col = sampled ? 0 : pl.s0_cols;          // bank rows filtered (or finished) so far
     sel.dense_n = pl.s0_cols;
     sel.dense_col0 = 0;
-    sel.tau_only = sampled ? 1 : 0;
     if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
     {
         ProfScope ps(MI_PROF_SELECT, (double)B * sel.dense_n * 4.0, s);
-        if (k <= mi::WSEL_MAX_K) hipLaunchKernelGGL((mi::wave_select_kernel<mi::SRC_DENSE>), dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, sel);
+        if (sampled) hipLaunchKernelGGL((mi::sample_tau_kernel<S0_COLS / 64>), dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, sel);
+        else if (k <= mi::WSEL_MAX_K) hipLaunchKernelGGL((mi::wave_select_kernel<mi::SRC_DENSE>), dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, sel);
         else hipLaunchKernelGGL((mi::select_kernel<mi::SRC_DENSE>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, s, sel);
         HIP_CHECK(hipGetLastError());
     }
@@ -664,17 +664,26 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
         col += ncols;
         if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }
         {
-            // threshold refresh: wave-per-row merge for rows with few candidates, block sort for the rest
+            // threshold refresh.  k <= 256: one wave per row, selection in registers (bag_refresh_kernel).
+            // k > 256: wave-per-row counting merge for rows with few candidates, workgroup select for the rest.
             ProfScope ps(MI_PROF_SELECT, (double)B * k * 16.0, s);
-            sel.skip_small = 1;
             const dim3 mgrid((unsigned)ceil_div(B, 4));
-            if (k <= 256) hipLaunchKernelGGL((mi::merge_kernel<4>), mgrid, dim3(256), 0, s, sel);
-            else if (k <= 512) hipLaunchKernelGGL((mi::merge_kernel<8>), mgrid, dim3(256), 0, s, sel);
-            else hipLaunchKernelGGL((mi::merge_kernel<16>), mgrid, dim3(256), 0, s, sel);
-            HIP_CHECK(hipGetLastError());
-            if (k <= mi::WSEL_MAX_K) hipLaunchKernelGGL((mi::wave_select_kernel<mi::SRC_LIST>), dim3(1024), dim3(256), 0, s, sel);
-            else hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3(2048), dim3(mi::SEL_THREADS), 0, s, sel);
-            HIP_CHECK(hipGetLastError());
+            if (k <= mi::WSEL_MAX_K) {
+                switch ((k + 63) / 64) {
+                case 1: hipLaunchKernelGGL((mi::bag_refresh_kernel<1>), mgrid, dim3(256), 0, s, sel); break;
+                case 2: hipLaunchKernelGGL((mi::bag_refresh_kernel<2>), mgrid, dim3(256), 0, s, sel); break;
+                case 3: hipLaunchKernelGGL((mi::bag_refresh_kernel<3>), mgrid, dim3(256), 0, s, sel); break;
+                default: hipLaunchKernelGGL((mi::bag_refresh_kernel<4>), mgrid, dim3(256), 0, s, sel); break;
+                }
+                HIP_CHECK(hipGetLastError());
+            } else {
+                sel.skip_small = 1;
+                if (k <= 512) hipLaunchKernelGGL((mi::merge_kernel<8>), mgrid, dim3(256), 0, s, sel);
+                else hipLaunchKernelGGL((mi::merge_kernel<16>), mgrid, dim3(256), 0, s, sel);
+                HIP_CHECK(hipGetLastError());
+                hipLaunchKernelGGL((mi::select_kernel<mi::SRC_LIST>), dim3(2048), dim3(mi::SEL_THREADS), 0, s, sel);
+                HIP_CHECK(hipGetLastError());
+            }
         }
     }
     return MI_OK;

@@ -77,8 +77,6 @@ struct SelectParams {
     float *out_val;             // [B, k]
     long long *out_idx;         // [B, k]
     long long idx_base;
-    int tau_only;               // SRC_DENSE: the dense values are a SAMPLE of the bank -- only the threshold is kept
-                                // (topk_n stays 0: every bank row, the sampled ones included, goes through the filter once)
     int skip_small;             // SRC_LIST: rows with <= MERGE_MAX_NEW candidates were merged by merge_kernel
     // SRC_LIST work list: merge_kernel appends the rows it leaves to select_kernel (> MERGE_MAX_NEW
     // candidates) to big_rows and counts them in big_cnt[parity]; select_kernel<SRC_LIST> then runs a
@@ -304,12 +302,10 @@ __device__ __forceinline__ void select_row(const SelectParams &p, const int row,
         for (int i = tid; i < p.mask_words; i += SEL_THREADS) p.tmask[(long long)row * p.mask_words + i] = 0u;
     }
     if constexpr (SRC != SRC_GATHER) {
-        const bool keep = !(SRC == SRC_DENSE && p.tau_only);
-        if (keep)
-            for (int i = tid; i < n_cur; i += SEL_THREADS) p.topk[(long long)row * p.k + i] = keys[i];
+        for (int i = tid; i < n_cur; i += SEL_THREADS) p.topk[(long long)row * p.k + i] = keys[i];
         if (tid == 0) {
-            p.topk_n[row] = keep ? n_cur : 0;
-            // tau only ever rises: it stays at its initial -inf (or at the sample's threshold) until k keys are held
+            p.topk_n[row] = n_cur;
+            // tau only ever rises: it stays at its initial -inf (or at the bootstrap sample's threshold) until k keys are held
             if (n_cur >= p.k) p.tau[row] = key_value(keys[p.k - 1]);
         }
     }
@@ -601,12 +597,10 @@ __device__ __forceinline__ void wave_select_row(const SelectParams &p, const lon
     if constexpr (SRC == SRC_LIST) {
         for (int i = lane; i < p.mask_words; i += 64) p.tmask[row * p.mask_words + i] = 0u;
     }
-    const bool keep = !(SRC == SRC_DENSE && p.tau_only);
-    if (keep)
-        for (int i = lane; i < n_cur; i += 64) p.topk[row * p.k + i] = keys[i];
+    for (int i = lane; i < n_cur; i += 64) p.topk[row * p.k + i] = keys[i];
     if (lane == 0) {
-        p.topk_n[row] = keep ? n_cur : 0;
-        // tau only ever rises: it stays at its initial -inf (or at the sample's threshold) until k keys are held
+        p.topk_n[row] = n_cur;
+        // tau only ever rises: it stays at its initial -inf (or at the bootstrap sample's threshold) until k keys are held
         if (n_cur >= p.k) p.tau[row] = key_value(keys[p.k - 1]);
     }
     if (finalize) {
@@ -771,91 +765,189 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
 //
 // The kept keys are a BAG (unsorted, compact: slots [0, topk_n) of the row): between stages only the
 // threshold matters, the order is needed once, at the end.  A refresh is therefore a SELECTION, not a
-// sort, and it runs in registers:
+// sort, and it runs in registers.  The kernel is latency-, not bandwidth-bound (a row moves ~4 KB), so
+// it is built for many rows in flight (<= 64 VGPRs: 8 waves per SIMD, 4 KiB of LDS per wave) and a short
+// chain of dependent memory round trips:
 //   * the row's candidates are located by a per-tile exclusive prefix of the stage's counts (cnt2, through
-//     the row's tile bitmask) in a wave-private LDS window, candidate j finds its (tile, slot) by binary
-//     search, and every lane loads its candidates straight into registers -- all loads of a batch are in
-//     flight together (the lists are short and scattered: latency, not bandwidth, is the cost);
+//     the row's tile bitmask) in a wave-private LDS window; candidate j finds its (tile, slot) by binary
+//     search and every lane loads its candidates straight into registers, all loads of a batch in flight
+//     together; the kept keys are requested before that chain starts;
 //   * the k-th largest of kept + new keys comes from an MSB-first BINARY radix select on wave ballots: one
-//     ballot + popcount per register slot and key bit, only over the bits in which the keys differ at all,
-//     stopping when one key is left (about log2(keys) + a few steps); no LDS histogram, no atomics, no barrier;
+//     v_and + v_cmp + s_bcnt1 per register slot and key bit, only over the bits in which the keys differ at
+//     all, stopping when one key is left (about log2(keys) + a few steps); keys that drop out are zeroed in
+//     a working copy, so no activity mask is carried; no LDS histogram, no atomics, no barrier;
 //   * the survivors (exactly k: keys are distinct) are compacted through 2 KiB of wave-private LDS back into
 //     the bag; the final stage sorts that LDS copy (bitonic, wave-private) and emits (value, index).
-// This replaces the counting merge + LDS radix-select/compact/sort pair for k <= 256 (per stage of 16 384 rows:
-// ~140 us -> see DESIGN.md); k > 256 keeps the workgroup-per-row kernels above.
-constexpr int BAG_WIN = 1024;          // bank tiles per prefix window (4 KiB of LDS per wave)
+// This replaces the counting merge + LDS radix-select/compact/sort pair for k <= 256; k > 256 keeps the
+// workgroup-per-row kernels above.
+constexpr int BAG_WIN = 512;           // bank tiles per prefix window (2 KiB of LDS per wave)
 constexpr int BAG_TPL = BAG_WIN / 64;  // consecutive tiles per lane
-constexpr int BAG_NSLOT = 12;          // new candidates per lane and batch (768 per batch)
+constexpr int BAG_NSLOT = 4;           // new candidates per lane and batch (256 per batch)
 
 struct BagSmem {
     unsigned pre[BAG_WIN];             // exclusive prefix of the window's per-tile candidate counts
     unsigned long long bag[256];       // survivors of a batch, compacted; sorted in place by the final stage
 };
 
-// rank-th largest (1-based) of the non-zero keys held in registers by one wave: pk[KPL] (kept) and nk[ns] (new).
-// Needs nz >= rank >= 1 non-zero keys, all distinct.  Every lane returns the same key.
-template <int KPL>
-__device__ __forceinline__ unsigned long long bag_select_kth(const unsigned long long (&pk)[KPL],
-                                                             const unsigned long long (&nk)[BAG_NSLOT], int ns,
-                                                             int nz, int rank)
+// wave-uniform values the compiler cannot prove uniform (results of cross-lane ops, per-lane loads of one
+// address): moved to scalar registers so that the loops and branches on them are scalar
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v, unsigned old = 0u)
 {
-    unsigned long long a = ~0ull, o = 0ull;
-#pragma unroll
-    for (int j = 0; j < KPL; ++j)
-        if (pk[j]) { a &= pk[j]; o |= pk[j]; }
-#pragma unroll
-    for (int s2 = 0; s2 < BAG_NSLOT; ++s2)
-        if (s2 < ns && nk[s2]) { a &= nk[s2]; o |= nk[s2]; }
-    a = wave_and64(a);
-    o = wave_or64(o);
-    const unsigned long long var = a ^ o;                       // bits in which the keys differ at all
-    if (var == 0ull) return a;                                  // one key
-    unsigned act = 0u;                                          // bit j: pk[j] still a candidate; bit KPL + s: nk[s]
-#pragma unroll
-    for (int j = 0; j < KPL; ++j) act |= (pk[j] != 0ull) ? (1u << j) : 0u;
-#pragma unroll
-    for (int s2 = 0; s2 < BAG_NSLOT; ++s2) act |= (s2 < ns && nk[s2] != 0ull) ? (1u << (KPL + s2)) : 0u;
-    int r = rank, n_act = nz;
-    for (int bit = 63 - __clzll((long long)var); bit >= 0; --bit) {
-        if (!((var >> bit) & 1ull)) continue;                   // every key agrees on this bit (wave-uniform)
-        const bool hiw = bit >= 32;
-        const unsigned msk = 1u << (bit & 31);
-        unsigned ones = 0u;                                     // slots that are active AND have the bit set
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+// AND / OR over the 64 lanes (result wave-uniform, in scalar registers): xor-butterfly inside each 16-lane
+// DPP row (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the four rows by readlane
+__device__ __forceinline__ unsigned wave_and_u32(unsigned v)
+{
+    v &= dpp_u32<0xB1>(v); v &= dpp_u32<0x4E>(v); v &= dpp_u32<0x141>(v); v &= dpp_u32<0x140>(v);
+    return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) & __builtin_amdgcn_readlane((int)v, 16) &
+                      __builtin_amdgcn_readlane((int)v, 32) & __builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
+{
+    v |= dpp_u32<0xB1>(v); v |= dpp_u32<0x4E>(v); v |= dpp_u32<0x141>(v); v |= dpp_u32<0x140>(v);
+    return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
+                      __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+}
+// inclusive prefix sum over the 64 lanes + the wave total (uniform): row_shr 1/2/4/8 inside the DPP rows
+// (lanes shifted in from outside the row contribute `old` = 0), then the row totals by readlane
+__device__ __forceinline__ int wave_scan_incl(int v, int lane, int &total)
+{
+    unsigned x = (unsigned)v;
+    x += dpp_u32<0x111>(x); x += dpp_u32<0x112>(x); x += dpp_u32<0x114>(x); x += dpp_u32<0x118>(x);
+    const int t0 = __builtin_amdgcn_readlane((int)x, 15), t1 = __builtin_amdgcn_readlane((int)x, 31);
+    const int t2 = __builtin_amdgcn_readlane((int)x, 47), t3 = __builtin_amdgcn_readlane((int)x, 63);
+    const int r = lane >> 4;
+    total = t0 + t1 + t2 + t3;
+    return (int)x + (r > 0 ? t0 : 0) + (r > 1 ? t1 : 0) + (r > 2 ? t2 : 0);
+}
+
+// One phase of the MSB-first binary radix select over the 32-bit words w[NK] of one wave (0 = not a candidate):
+// narrows the candidates to those that share the rank-th largest word's bits, over the bits set in `var` (the bits
+// in which the words differ at all), until one candidate is left or the bits run out.  Words that drop out are
+// zeroed.  r: rank among the candidates (1-based), n_act: candidates; both are updated.  Per slot and bit:
+// v_bfe_i32 + v_cmp (+ s_bcnt1) to count, v_and to narrow.
+template <int NK>
+__device__ __forceinline__ void radix_narrow_u32(unsigned (&w)[NK], unsigned var, int &r, int &n_act)
+{
+    if (n_act <= 1 || !var) return;
+    for (int bit = 31 - __builtin_clz(var); bit >= 0 && n_act > 1; --bit) {
+        if (!(var & (1u << bit))) continue;                     // every word agrees on this bit (scalar branch)
         int cnt1 = 0;
+        if constexpr (NK <= 8) {
+            int mb[NK];                                         // -1 where the bit is set, else 0
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            const unsigned w = hiw ? (unsigned)(pk[j] >> 32) : (unsigned)pk[j];
-            const bool m = ((act >> j) & 1u) && (w & msk);
-            cnt1 += __popcll(__ballot(m));
-            ones |= m ? (1u << j) : 0u;
-        }
+            for (int i = 0; i < NK; ++i) { mb[i] = __builtin_amdgcn_sbfe((int)w[i], bit, 1); cnt1 += __popcll(__ballot(mb[i] != 0)); }
+            if (cnt1 >= r) {                                    // the rank-th largest has this bit set: zeros drop out
+                n_act = cnt1;
 #pragma unroll
-        for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
-            if (s2 < ns) {                                      // wave-uniform
-                const unsigned w = hiw ? (unsigned)(nk[s2] >> 32) : (unsigned)nk[s2];
-                const bool m = ((act >> (KPL + s2)) & 1u) && (w & msk);
-                cnt1 += __popcll(__ballot(m));
-                ones |= m ? (1u << (KPL + s2)) : 0u;
+                for (int i = 0; i < NK; ++i) w[i] &= (unsigned)mb[i];
+            } else {                                            // it has the bit clear: ones drop out
+                r -= cnt1; n_act -= cnt1;
+#pragma unroll
+                for (int i = 0; i < NK; ++i) w[i] &= ~(unsigned)mb[i];
+            }
+        } else {                                                // many slots: recompute the bit instead of keeping NK masks
+#pragma unroll
+            for (int i = 0; i < NK; ++i) cnt1 += __popcll(__ballot(__builtin_amdgcn_sbfe((int)w[i], bit, 1) != 0));
+            if (cnt1 >= r) {
+                n_act = cnt1;
+#pragma unroll
+                for (int i = 0; i < NK; ++i) w[i] &= (unsigned)__builtin_amdgcn_sbfe((int)w[i], bit, 1);
+            } else {
+                r -= cnt1; n_act -= cnt1;
+#pragma unroll
+                for (int i = 0; i < NK; ++i) w[i] &= ~(unsigned)__builtin_amdgcn_sbfe((int)w[i], bit, 1);
             }
         }
-        if (cnt1 >= r) { act = ones; n_act = cnt1; }            // the rank-th largest has this bit set
-        else { r -= cnt1; act &= ~ones; n_act -= cnt1; }
-        if (n_act <= 1) break;
     }
-    unsigned long long found = 0ull;                            // the one key left (distinct keys)
+}
+
+// rank-th largest (1-based) of the non-zero keys held in registers by one wave (NK slots per lane: kept keys and
+// new ones alike).  Needs nz >= rank >= 1 non-zero keys, all distinct.  Every lane returns the same key.
+template <int NK>
+__device__ __forceinline__ unsigned long long bag_select_kth(const unsigned long long (&key)[NK], int nz, int rank)
+{
+    unsigned alo = ~0u, ahi = ~0u, olo = 0u, ohi = 0u;
+    unsigned w[NK];                                             // working copy: the key word under test, 0 = dropped out
 #pragma unroll
-    for (int j = 0; j < KPL; ++j)
-        if ((act >> j) & 1u) found = pk[j];
+    for (int i = 0; i < NK; ++i) {
+        const unsigned lo = (unsigned)key[i], hi = (unsigned)(key[i] >> 32);
+        w[i] = hi;                                              // hi = orderable(value) is never 0 for a real key
+        if (key[i]) { alo &= lo; ahi &= hi; olo |= lo; ohi |= hi; }
+    }
+    alo = wave_and_u32(alo); ahi = wave_and_u32(ahi);
+    olo = wave_or_u32(olo); ohi = wave_or_u32(ohi);
+    int r = rank, n_act = nz;
+    radix_narrow_u32<NK>(w, ahi ^ ohi, r, n_act);               // by value ...
+    if (n_act > 1) {                                            // ... equal values: go on through the row word
 #pragma unroll
-    for (int s2 = 0; s2 < BAG_NSLOT; ++s2)
-        if (s2 < ns && ((act >> (KPL + s2)) & 1u)) found = nk[s2];
-    return wave_or64(found);
+        for (int i = 0; i < NK; ++i) w[i] = w[i] ? (unsigned)key[i] : 0u;      // 0xFFFFFFFF - row is never 0 (row < 2^31)
+        radix_narrow_u32<NK>(w, alo ^ olo, r, n_act);
+    }
+    // one key is left (keys are distinct): the slot whose working word is still non-zero
+    unsigned flo = 0u, fhi = 0u;
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+        if (w[i]) { flo = (unsigned)key[i]; fhi = (unsigned)(key[i] >> 32); }
+    const unsigned long long has = __ballot((flo | fhi) != 0u);
+    const int src = has ? __builtin_ctzll(has) : 0;
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)fhi, src) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)flo, src);
+}
+
+// First threshold from the bootstrap SAMPLE (mi_knn_topk, sampled mode): tau[row] = k-th largest of the row's NV * 64
+// dense similarities (duplicates count, NaNs do not), left at -inf when fewer than k are real.  One wave per row, the
+// values in registers (NV per lane), the same ballot radix select on the order-preserving word; nothing else is
+// kept -- the sampled bank rows go through the filter like every other row.
+template <int NV>
+__global__ __launch_bounds__(256) void sample_tau_kernel(const SelectParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B) return;
+    static_assert(NV % 4 == 0, "float4 loads");
+    const float4 *d = (const float4 *)((const float *)p.cand + row * 2 * p.cap);      // dense row: NV * 64 floats
+    unsigned w[NV];
+    unsigned a = ~0u, o = 0u;
+    int nz = 0;
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) {
+        const float4 v = d[j * 64 + lane];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned x = (f[u] != f[u]) ? 0u : orderable_f32(f[u]);             // NaN: not a candidate
+            w[4 * j + u] = x;
+            if (x) { a &= x; o |= x; }
+            nz += __popcll(__ballot(x != 0u));
+        }
+    }
+    if (nz < p.k) return;                                       // tau stays -inf
+    a = wave_and_u32(a);
+    o = wave_or_u32(o);
+    int r = p.k, n_act = nz;
+    radix_narrow_u32<NV>(w, a ^ o, r, n_act);
+    unsigned f = 0u;                                            // any word still standing is the answer (equal values all stand)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) f |= w[i];
+    const unsigned long long has = __ballot(f != 0u);
+    const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)f, has ? __builtin_ctzll(has) : 0);
+    if (lane == 0) {
+        p.tau[row] = from_orderable(kth);
+        p.topk_n[row] = 0;
+    }
 }
 
 template <int KPL>
-__global__ __launch_bounds__(256) void bag_refresh_kernel(const SelectParams p)
+__global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams p)
 {
     __shared__ BagSmem smem[4];
+    constexpr int NK = KPL + BAG_NSLOT;                         // key[0, KPL): kept bag; key[KPL, NK): new candidates
+    constexpr int BATCH = BAG_NSLOT * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wv;
     if (row >= p.B) return;
@@ -865,23 +957,52 @@ __global__ __launch_bounds__(256) void bag_refresh_kernel(const SelectParams p)
     unsigned *tm = p.tmask + row * p.mask_words;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
 
-    unsigned long long pk[KPL];
-    bool have_pk = false, any = false;
-    int n_cur = 0;
+    unsigned long long key[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) key[i] = 0ull;
+    bool have_bag = false, any = false;
+    int n_cur = 0, fill = 0, nz_new = 0;                        // fill: batch positions taken; nz_new: real keys among them
     unsigned long long kth_last = 0ull;
     auto load_bag = [&]() {                                     // deferred: rows without candidates never read it
-        n_cur = p.topk_n[row];
+        n_cur = uniform_i32(p.topk_n[row]);
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) pk[j] = (j * 64 + lane) < n_cur ? p.topk[row * k + j * 64 + lane] : 0ull;
-        have_pk = true;
+        for (int j = 0; j < KPL; ++j) key[j] = (j * 64 + lane) < n_cur ? p.topk[row * k + j * 64 + lane] : 0ull;
+        have_bag = true;
+    };
+    // fold the batch in registers into the bag: select the k-th largest of kept + new, compact the survivors
+    auto fold = [&]() {
+        const int nz = n_cur + nz_new;
+        const int keep = nz < k ? nz : k;
+        unsigned long long kth = 1ull;                          // fewer than k keys: keep every real one
+        if (nz >= k) { kth = bag_select_kth<NK>(key, nz, k); kth_last = kth; }
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const bool take = key[i] >= kth && key[i] != 0ull;
+            const unsigned long long bal = __ballot(take);
+            const int at = base + __popcll(bal & ltmask);
+            if (take && at < k) sm.bag[at] = key[i];            // exactly `keep` survivors (distinct keys); `< k` guards LDS regardless
+            base += __popcll(bal);
+        }
+        wave_step();
+        n_cur = keep;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) key[j] = (j * 64 + lane) < n_cur ? sm.bag[j * 64 + lane] : 0ull;
+#pragma unroll
+        for (int i = KPL; i < NK; ++i) key[i] = 0ull;
+        wave_step();
+        fill = 0;
+        nz_new = 0;
+        any = true;
     };
 
     for (int w0 = 0; w0 < p.ntiles; w0 += BAG_WIN) {
-        // this lane's BAG_TPL consecutive tiles of the window: one 16-bit piece of the row's tile mask
+        // this lane's BAG_TPL consecutive tiles of the window: one 8-bit piece of the row's tile mask
         const int t0 = w0 + lane * BAG_TPL;
         unsigned bits = 0u;
-        if (t0 < p.ntiles) bits = (tm[t0 >> 5] >> (t0 & 31)) & 0xFFFFu;
+        if (t0 < p.ntiles) bits = (tm[t0 >> 5] >> (t0 & 31)) & ((1u << BAG_TPL) - 1u);
         if (__ballot(bits != 0u) == 0ull) continue;             // no candidate of this row in the window
+        if (!have_bag) load_bag();                              // in flight beside the count / candidate loads below
         int cnt[BAG_TPL];
         int mine = 0;
 #pragma unroll
@@ -891,13 +1012,8 @@ __global__ __launch_bounds__(256) void bag_refresh_kernel(const SelectParams p)
             cnt[i] = c;
             mine += c;
         }
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o2 = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o2;
-        }
-        const int cw = __shfl(incl, 63, 64);                    // candidates of the row in this window
+        int cw;                                                 // candidates of the row in this window
+        const int incl = wave_scan_incl(mine, lane, cw);
         if (cw == 0) continue;
         {
             unsigned run = (unsigned)(incl - mine);
@@ -908,86 +1024,49 @@ __global__ __launch_bounds__(256) void bag_refresh_kernel(const SelectParams p)
             }
         }
         wave_step();
-        if (!have_pk) load_bag();
-        for (int j0 = 0; j0 < cw; j0 += BAG_NSLOT * 64) {
-            const int nb = (cw - j0) < BAG_NSLOT * 64 ? (cw - j0) : BAG_NSLOT * 64;
-            const int ns = (nb + 63) >> 6;
-            // candidate j -> (tile = largest tau with pre[tau] <= j, slot j - pre[tau]); all loads issued together
-            unsigned long long nk[BAG_NSLOT];
-            uint2 cd[BAG_NSLOT];
+        for (int j0 = 0; j0 < cw;) {
+            // batch position q = s * 64 + lane takes candidate j0 + q - fill of the window (positions < fill are taken)
+            const int take_n = (cw - j0) < (BATCH - fill) ? (cw - j0) : (BATCH - fill);
             int pos[BAG_NSLOT];
 #pragma unroll
             for (int s2 = 0; s2 < BAG_NSLOT; ++s2) pos[s2] = 0;
+            // candidate j -> tile = largest tau with pre[tau] <= j, slot j - pre[tau]
 #pragma unroll
             for (int step = BAG_WIN / 2; step > 0; step >>= 1) {
 #pragma unroll
                 for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
-                    if (s2 < ns) {
-                        const unsigned j = (unsigned)(j0 + s2 * 64 + lane);
-                        if (sm.pre[pos[s2] + step] <= j) pos[s2] += step;
-                    }
+                    const int q = s2 * 64 + lane - fill;
+                    if (q >= 0 && q < take_n && sm.pre[pos[s2] + step] <= (unsigned)(j0 + q)) pos[s2] += step;
                 }
+            }
+            uint2 cd[BAG_NSLOT];
+#pragma unroll
+            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
+                const int q = s2 * 64 + lane - fill;
+                cd[s2] = make_uint2(0u, 0xFFFFFFFFu);
+                if (q >= 0 && q < take_n)
+                    cd[s2] = p.cand[row * p.cap + (long long)(w0 + pos[s2]) * 256 + (j0 + q - (int)sm.pre[pos[s2]])];
             }
 #pragma unroll
             for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
-                cd[s2] = make_uint2(0x7FC00000u, 0u);                                   // NaN: key 0 (empty)
-                if (s2 < ns) {
-                    const int j = j0 + s2 * 64 + lane;
-                    if (j < j0 + nb) {
-                        const int e = j - (int)sm.pre[pos[s2]];
-                        cd[s2] = p.cand[row * p.cap + (long long)(w0 + pos[s2]) * 256 + e];
-                    }
-                }
+                const int q = s2 * 64 + lane - fill;
+                if (q >= 0 && q < take_n) key[KPL + s2] = make_key(__uint_as_float(cd[s2].x), cd[s2].y);
+                nz_new += __popcll(__ballot(q >= 0 && q < take_n && key[KPL + s2] != 0ull));
             }
-            int nz = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
-                nk[s2] = 0ull;
-                if (s2 < ns) {
-                    nk[s2] = make_key(__uint_as_float(cd[s2].x), cd[s2].y);
-                    nz += __popcll(__ballot(nk[s2] != 0ull));
-                }
-            }
-            nz += n_cur;
-            const int keep = nz < k ? nz : k;
-            unsigned long long kth = 1ull;                      // fewer than k keys: keep every real one
-            if (nz >= k) { kth = bag_select_kth<KPL>(pk, nk, ns, nz, k); kth_last = kth; }
-            // survivors -> compact LDS bag (exactly `keep`: keys are distinct; `< k` guards the LDS block regardless)
-            wave_step();
-            int base = 0;
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) {
-                const bool take = pk[j] >= kth && pk[j] != 0ull;
-                const unsigned long long bal = __ballot(take);
-                const int at = base + __popcll(bal & ltmask);
-                if (take && at < k) sm.bag[at] = pk[j];
-                base += __popcll(bal);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < BAG_NSLOT; ++s2) {
-                if (s2 < ns) {
-                    const bool take = nk[s2] >= kth && nk[s2] != 0ull;
-                    const unsigned long long bal = __ballot(take);
-                    const int at = base + __popcll(bal & ltmask);
-                    if (take && at < k) sm.bag[at] = nk[s2];
-                    base += __popcll(bal);
-                }
-            }
-            wave_step();
-            n_cur = keep;
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) pk[j] = (j * 64 + lane) < n_cur ? sm.bag[j * 64 + lane] : 0ull;
-            any = true;
+            fill += take_n;
+            j0 += take_n;
+            if (fill == BATCH) fold();
         }
         wave_step();                                            // sm.pre is rewritten by the next window
     }
+    if (fill > 0) fold();
 
     if (any) {
         for (int i = lane; i < p.mask_words; i += 64) tm[i] = 0u;           // consumed: the next stage starts clear
         if (!finalize) {
 #pragma unroll
             for (int j = 0; j < KPL; ++j)
-                if ((j * 64 + lane) < n_cur) p.topk[row * k + j * 64 + lane] = pk[j];
+                if ((j * 64 + lane) < n_cur) p.topk[row * k + j * 64 + lane] = key[j];
             if (lane == 0) {
                 p.topk_n[row] = n_cur;
                 if (kth_last) p.tau[row] = key_value(kth_last);             // tau only ever rises
@@ -995,20 +1074,20 @@ __global__ __launch_bounds__(256) void bag_refresh_kernel(const SelectParams p)
         }
     }
     if (finalize) {
-        if (!have_pk) load_bag();
+        if (!have_bag) load_bag();
         int n2 = 64;
         while (n2 < n_cur) n2 <<= 1;
         wave_step();
 #pragma unroll
         for (int j = 0; j < KPL; ++j)
-            if (j * 64 < n2) sm.bag[j * 64 + lane] = pk[j];                 // zeros pad up to n2
+            if (j * 64 < n2) sm.bag[j * 64 + lane] = key[j];                // zeros pad up to n2
         wave_step();
         wave_bitonic_sort_desc(sm.bag, n2, lane);
         for (int i = lane; i < k; i += 64) {
             const bool ok = i < n_cur;
-            const unsigned long long key = ok ? sm.bag[i] : 0ull;
-            p.out_val[row * k + i] = ok ? key_value(key) : -INFINITY;
-            p.out_idx[row * k + i] = ok ? p.idx_base + (long long)key_row(key) : -1ll;
+            const unsigned long long kk = ok ? sm.bag[i] : 0ull;
+            p.out_val[row * k + i] = ok ? key_value(kk) : -INFINITY;
+            p.out_idx[row * k + i] = ok ? p.idx_base + (long long)key_row(kk) : -1ll;
         }
     }
 }
