@@ -786,7 +786,14 @@ int mi_knn_vote(const float *val, const int64_t *idx, const int64_t *labels, int
     if (k < 1 || k > MI_MAX_K) return fail(MI_ERR_UNSUPPORTED, "mi_knn_vote: k=%d outside [1, %d]", k, MI_MAX_K);
     if (classes < 1 || classes > MI_MAX_CLASSES) return fail(MI_ERR_UNSUPPORTED, "mi_knn_vote: classes=%d outside [1, %d]", classes, MI_MAX_CLASSES);
     if (!(knn_t > 0.f)) return fail(MI_ERR_ARG, "mi_knn_vote: temperature must be positive");
-    mi::VoteParams vp{val, (const long long *)idx, (const long long *)labels, n_labels, k, classes, knn_t, out_scores, (long long *)out_rank};
+    mi::VoteParams vp{B, val, (const long long *)idx, (const long long *)labels, n_labels, k, classes, knn_t, out_scores, (long long *)out_rank};
+    if (k <= 256 && classes <= mi::VOTE_WAVE_MAX_C) {
+        // wave-per-row LDS histogram (every configuration of the reference: k = 200, 10 / 100 / 1000 classes)
+        const size_t lds = mi::vote_wave_lds_bytes(classes);
+        hipLaunchKernelGGL(mi::vote_wave_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), lds, (hipStream_t)stream, vp);
+        HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
     const size_t dyn = (size_t)round_up((int64_t)classes * 2, 16);
     if (dyn > 48 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void *)mi::vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
