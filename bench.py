@@ -53,7 +53,12 @@ def parse():
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--temperature", type=float, default=0.1)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
-    ap.add_argument("--query-chunk", type=int, default=16384)
+    ap.add_argument("--query-chunk", type=int, default=0, help="query rows per fused top-k call; 0 = by shard size (sharded.auto_query_chunk)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="G",
+                    help="one GPU only: do what ONE rank of a G-rank row-sharded job does -- all queries against a bank of "
+                         "--bank / G rows, then merge (G candidate blocks) + vote for 1 / G of the queries; no exchange "
+                         "(tools/shard_cost.sh: upper bound of the scaling efficiency)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel clock measurement after the timed region")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the query chunks alternate between")
     ap.add_argument("--shard", choices=["rows", "queries"], default="rows",
                     help="rows: the bank is row-sharded (north star, default).  queries: comparison row of SURVEY 8(e) -- "
@@ -132,7 +137,12 @@ def main():
 
     B, N, D, C, k, T = args.queries, args.bank, args.dim, args.classes, args.k, args.temperature
     by_rows = args.shard == "rows"
+    emu = args.emulate_rank_of
+    if emu and (world > 1 or not by_rows or N % emu):
+        raise SystemExit("--emulate-rank-of is a one-GPU, row-sharded emulation and needs bank rows divisible by G")
     lo, hi = sharded.shard_bounds(N, world, rank) if by_rows else (0, N)
+    if emu:
+        lo, hi = sharded.shard_bounds(N, emu, 0)                            # rank 0's shard of the G-rank job
     labels = torch.randint(0, C, (N,), generator=torch.Generator(device=device).manual_seed(2), device=device)
     if args.data == "random":
         bank_rows = unit_rows(hi - lo, D, 1000 + (rank if by_rows else 0), device)   # this rank's shard (or the whole bank), [n_local, D] f32
@@ -146,12 +156,30 @@ def main():
         feature = clustered_rows(qlab, D, centroids, 1, device)
     torch.cuda.synchronize()
 
+    def emulated_rank_step():
+        """Rank 0 of an `emu`-rank job without the exchange: local candidates for ALL queries, then merge + vote for
+        its 1 / emu slice of every chunk (the other ranks' candidate blocks are stood in for by its own, re-based so
+        that the keys stay distinct)."""
+        knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk or None)
+        outs = []
+        for s0, e0 in sharded.chunk_bounds(B, knn.query_chunk):
+            val, idx = knn._local_candidates(feature[s0:e0], k)
+            a, b2 = sharded.shard_bounds(e0 - s0, emu, 0)
+            cv = val[a:b2].unsqueeze(0).expand(emu, -1, -1).contiguous()
+            ci = torch.stack([idx[a:b2] + g * (hi - lo) for g in range(emu)])
+            mv, mi = ica.knn_merge(cv, ci, k)
+            outs.append(ica.knn_vote(mv, mi, labels, C, T, check=False))
+        ranking = torch.cat(outs, 0)
+        return ranking[:, 0].contiguous(), ranking
+
     def step():
+        if emu:
+            return emulated_rank_step()
         if by_rows:
-            knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk,
+            knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk or None,
                                      n_streams=args.streams)
         else:
-            knn = sharded.QuerySlicedKnn(bank_rows, compute_dtype=args.dtype, query_chunk=args.query_chunk)
+            knn = sharded.QuerySlicedKnn(bank_rows, compute_dtype=args.dtype, query_chunk=args.query_chunk or 16384)
         top1 = knn.predict(feature, labels, C, k, T, gather="top1")
         return top1, knn.local_ranking
 
@@ -177,19 +205,41 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert tuple(pred.shape) == (B,) and ranking.shape[1] == C          # top-1 everywhere, full ranking with the slice owner
+    assert ranking.shape[1] == C and (emu or tuple(pred.shape) == (B,))   # top-1 everywhere, full ranking with the slice owner
+
+    # In-kernel clock of the dominant kernel (MI355X lowers its clock under MFMA load: MI355X_MICROARCH.md, DVFS
+    # give-back item 6): two more untimed steps through the STAMPED instantiation of the same kernel, right after
+    # the timed region; clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the workgroups.
+    clock_ghz = None
+    if rank == 0 and not args.no_clock_probe:
+        stamps = torch.zeros((16384, 2), dtype=torch.int64, device=device)
+        _lib.check(_lib.lib().mi_profile_clock(stamps.data_ptr(), stamps.shape[0]), "mi_profile_clock")
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(_lib.lib().mi_profile_clock(None, 0), "mi_profile_clock")
+        st = stamps.cpu().double()
+        ok = st[:, 1] > 0
+        if bool(ok.any()):
+            clock_ghz = float((st[ok, 0] / st[ok, 1]).median()) * 0.1
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         achieved = sim_flops / (sim_ms * 1e-3) / 1e12 if sim_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
-        traffic = None
+        # traffic is NOT measured in this run: it is the recorded result of the rocprofv3 --pmc passes named in
+        # traffic_source (PMC collection needs its own profiled runs); null when no record matches this workload
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not emu:
             try:
-                tj = json.load(open(tpath))
-                key = f"{args.dtype}:{B}x{N}x{D}:g{world}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(f"{args.dtype}:{B}x{N}x{D}:g{world}", {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = rec.get("source") if traffic is not None else None
             except Exception:
                 traffic = None
         out = {
@@ -208,13 +258,20 @@ def main():
                             f"{C} classes, {args.dtype} MFMA with fp32 accumulate; step = pack + fused sim/top-k"
                             f"{' + RCCL candidate all-to-all + merge' if world > 1 and by_rows else ''} + vote + ranking",
                 "queries": B, "bank_rows": N, "dim": D, "k": k, "classes": C,
+                **({"emulated_rank_of": emu, "rank_bank_rows": hi - lo} if emu else {}),
                 "parallelism": (f"bank rows sharded over {world} GPU(s); merge/vote sharded by query slice; top-1 labels all-gathered"
                                 if by_rows else
                                 f"comparison row: whole bank on each of {world} GPU(s), queries sliced, no candidate exchange; top-1 labels all-gathered"),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic,
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
+                "sustained_clock_ghz": clock_ghz, "spec_clock_ghz": 2.4,
+                "peak_at_sustained_clock": peak * clock_ghz / 2.4 if clock_ghz else None,
+                "frac_of_sustained": achieved / (peak * clock_ghz / 2.4) if clock_ghz else None,
+                "clock_source": ("in-kernel s_memtime / s_memrealtime stamps of a stamped instantiation of the same kernel, "
+                                 "2 untimed steps right after the timed region, median over workgroups (mi_profile_clock)"
+                                 if clock_ghz else None),
                 "kernel": "mi::sim_kernel (fused similarity GEMM + top-k filter)",
                 "launches": sim_launches, "avg_launch_ms": sim_ms / max(sim_launches, 1),
                 "algorithmic_flops_per_launch": sim_flops / max(sim_launches, 1),

@@ -15,7 +15,7 @@ MI_MAX_K, MI_MAX_CLASSES = 1024, 65536
 ABI_VERSION = 7
 
 EXPORTS = [
-    "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes",
+    "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_profile_clock", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes", "mi_knn_topk_workspace_bytes_for_budget",
     "mi_knn_topk", "mi_knn_topk_static", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
     "mi_moco_fwd", "mi_moco_bwd", "mi_queue_push_stash", "mi_bank_append_normalized", "mi_queue_push_wrap", "mi_soft_knn_workspace_bytes", "mi_soft_knn", "mi_kth_largest",
 ]
@@ -44,12 +44,15 @@ def lib() -> ctypes.CDLL:
     L.mi_profile_enable.restype, L.mi_profile_enable.argtypes = i32, [i32]
     L.mi_profile_collect.restype = i32
     L.mi_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
+    L.mi_profile_clock.restype, L.mi_profile_clock.argtypes = i32, [p, i64]
     L.mi_pack_rows.restype = i32
     L.mi_pack_rows.argtypes = [p, i64, i32, i64, i64, i32, p, i64, p]
     L.mi_bank_append_normalized.restype = i32
     L.mi_bank_append_normalized.argtypes = [p, i64, i64, i64, i32, p, i64, i64, i64, f32, p]
     L.mi_knn_topk_workspace_bytes.restype = sz
     L.mi_knn_topk_workspace_bytes.argtypes = [i64, i64, i32]
+    L.mi_knn_topk_workspace_bytes_for_budget.restype = sz
+    L.mi_knn_topk_workspace_bytes_for_budget.argtypes = [i64, i64, i32, sz]
     L.mi_knn_topk.restype = i32
     L.mi_knn_topk.argtypes = [p, i64, p, i64, i32, i64, i64, i64, i32, i64, p, p, p, sz, p]
     L.mi_knn_topk_static.restype = i32

@@ -264,15 +264,22 @@ __global__ void scatter_rows_kernel(char *__restrict__ bank, long long K, long l
     }
 }
 
-// MoCo forward, step 2: fold the per-tile (max, sumexp) partials and the positive logit.
+// MoCo forward, step 2: fold the per-tile (max, sumexp) partials and the positive logit, and -- in the
+// workgroup that finishes last -- the mean over the rows: one launch instead of two (a dependent launch costs
+// ~2-10 us of dispatch gap at this size, the whole forward is ~50 us).
 // 256 threads = 16 rows x 16 groups; group g folds tiles g, g+16, ... of its row (16 rows of one
 // tile = one coalesced 128-byte read) and columns g*D/16.. of q.key, then the groups meet in LDS.
+// Hand-off of the per-block sums (MI355X_MICROARCH.md, inter-workgroup visibility, counter form): lane 0 stores its
+// block's sum write-through (sc1), waits for the store, then adds to the arrival counter (agent scope); the block
+// whose add returns the last ticket reads every block sum with sc1 loads, adds them in block order (deterministic)
+// and resets the counter.  The counter is zeroed by the preceding similarity kernel (plain store, kernel boundary).
 __global__ __launch_bounds__(256) void moco_combine_kernel(const float *q, const float *key, int b, int D,
                                                           const float2 *part, int nparts, int lse_ld,
                                                           float inv_t, float *lse, float *lpos,
-                                                          float *row_loss)
+                                                          float *block_sum, unsigned *arrived, float *loss)
 {
     __shared__ float s_m[16][17], s_s[16][17], s_d[16][17];
+    __shared__ float s_loss[16];
     const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int row = blockIdx.x * 16 + r;
     float m = -INFINITY, sum = 0.f, d = 0.f;
@@ -291,34 +298,39 @@ __global__ __launch_bounds__(256) void moco_combine_kernel(const float *q, const
     s_s[r][g] = sum;
     s_d[r][g] = d;
     __syncthreads();
-    if (g == 0 && row < b) {
-        float dd = 0.f;
-        for (int i = 0; i < 16; ++i) dd += s_d[r][i];
-        const float lp = dd * inv_t;
-        float mm = lp;
-        for (int i = 0; i < 16; ++i) mm = fmaxf(mm, s_m[r][i]);
-        float ss = expf(lp - mm);
-        for (int i = 0; i < 16; ++i)
-            if (s_s[r][i] > 0.f) ss += s_s[r][i] * expf(s_m[r][i] - mm);
-        const float l = mm + logf(ss);
-        lse[row] = l;
-        lpos[row] = dd;
-        row_loss[row] = l - lp;
+    if (g == 0) {
+        float rl = 0.f;
+        if (row < b) {
+            float dd = 0.f;
+            for (int i = 0; i < 16; ++i) dd += s_d[r][i];
+            const float lp = dd * inv_t;
+            float mm = lp;
+            for (int i = 0; i < 16; ++i) mm = fmaxf(mm, s_m[r][i]);
+            float ss = expf(lp - mm);
+            for (int i = 0; i < 16; ++i)
+                if (s_s[r][i] > 0.f) ss += s_s[r][i] * expf(s_m[r][i] - mm);
+            const float l = mm + logf(ss);
+            lse[row] = l;
+            lpos[row] = dd;
+            rl = l - lp;
+        }
+        s_loss[r] = rl;
     }
-}
-
-__global__ __launch_bounds__(256) void mean_kernel(const float *x, int n, float *out)
-{
-    __shared__ float s[256];
-    float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) a += x[i];
-    s[threadIdx.x] = a;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        float bs = 0.f;
+        for (int i = 0; i < 16; ++i) bs += s_loss[i];
+        __hip_atomic_store(block_sum + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: write-through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            float tot = 0.f;
+            for (unsigned i = 0; i < gridDim.x; ++i)
+                tot += __hip_atomic_load(block_sum + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 loads, block order
+            loss[0] = tot / (float)b;
+            __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (threadIdx.x == 0) out[0] = s[0] / (float)n;
 }
 
 // --------------------------------------------------------------------------- top-k plan
@@ -415,6 +427,11 @@ int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t left)      // left
     return n;
 }
 
+// mi_profile_clock: when a stamp buffer is registered, filter launches run the STAMP instantiation of the kernel
+std::mutex g_stamp_mu;
+unsigned long long *g_stamp_buf = nullptr;
+int g_stamp_cap = 0;
+
 template <int DT, int MODE>
 hipError_t launch_sim(const mi::SimParams &p_in, hipStream_t s)
 {
@@ -430,6 +447,15 @@ hipError_t launch_sim(const mi::SimParams &p_in, hipStream_t s)
     p.pn = (int)ceil_div(p.ntiles, 32 >> qsh);
     const int patches = p.pq * p.pn;
     const int grid = (int)ceil_div(patches, 8) * 256;
+    if constexpr (MODE == mi::MODE_FILTER) {
+        std::lock_guard<std::mutex> lk(g_stamp_mu);
+        if (g_stamp_buf) {
+            p.stamps = g_stamp_buf;
+            p.stamp_cap = g_stamp_cap;
+            hipLaunchKernelGGL((mi::sim_kernel<DT, MODE, true>), dim3(grid), dim3(mi::SIM_THREADS), 0, s, p);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((mi::sim_kernel<DT, MODE>), dim3(grid), dim3(mi::SIM_THREADS), 0, s, p);
     return hipGetLastError();
 }
@@ -482,6 +508,15 @@ int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *to
     if (total_ms) *total_ms = ms;
     if (launches) *launches = n;
     if (total_work) *total_work = work;
+    return MI_OK;
+}
+
+int mi_profile_clock(void *stamps, int64_t entries)
+{
+    if (stamps && (entries < 1 || entries > INT32_MAX || ((uintptr_t)stamps & 15))) return fail(MI_ERR_ARG, "mi_profile_clock: bad buffer");
+    std::lock_guard<std::mutex> lk(g_stamp_mu);
+    g_stamp_buf = (unsigned long long *)stamps;
+    g_stamp_cap = stamps ? (int)entries : 0;
     return MI_OK;
 }
 
@@ -543,8 +578,16 @@ int mi_bank_append_normalized(const float *src, int64_t ld_src, int64_t b, int64
 
 size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k)
 {
+    return mi_knn_topk_workspace_bytes_for_budget(B, N, k, (size_t)CAND_BUDGET_BYTES);
+}
+
+size_t mi_knn_topk_workspace_bytes_for_budget(int64_t B, int64_t N, int k, size_t candidate_bytes)
+{
     if (B <= 0 || N <= 0 || k <= 0 || k > MI_MAX_K || B > (1 << 30) || N > INT32_MAX - 2 * mi::TILE) return 0;
-    return make_plan(B, N, k, -1).total + 2048 + 4 * (size_t)round_up(B, mi::TILE);        // + the alignment slack make_plan reserves when it sizes from a byte count
+    const int64_t budget = candidate_bytes > ((size_t)1 << 46) ? ((int64_t)1 << 46) : (int64_t)candidate_bytes;
+    Plan pl = make_plan(B, N, k, budget);
+    if (pl.cap == 0) pl = make_plan(B, N, k, -1);             // below the minimum: the default (it covers the minimum)
+    return pl.total + 2048 + 4 * (size_t)round_up(B, mi::TILE);        // + the alignment slack make_plan reserves when it sizes from a byte count
 }
 
 }  // extern "C"
@@ -868,8 +911,8 @@ MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
     m.ntiles = (int)ceil_div(K, mi::TILE);
     m.lse_ld = m.b_pad;
     m.off_part = 0;
-    m.off_rowloss = (size_t)round_up((int64_t)m.ntiles * m.lse_ld * 8, 256);
-    m.fwd_total = m.off_rowloss + (size_t)round_up((int64_t)m.b_pad * 4, 256);
+    m.off_rowloss = (size_t)round_up((int64_t)m.ntiles * m.lse_ld * 8, 256);      // the arrival counter (own line) + per-block loss sums
+    m.fwd_total = m.off_rowloss + 256 + (size_t)round_up((int64_t)ceil_div(b, 16) * 4, 256);
     // backward: ~256 workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
     const int64_t qtiles = ceil_div(b, mi::MB_ROWS);
     const int64_t ktiles = ceil_div(K, mi::MB_ROWS);
@@ -917,12 +960,13 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
     sp.inv_t = 1.0f / temperature;
     sp.lse_part = (float2 *)(ws + mp.off_part);
     sp.lse_ld = mp.lse_ld;
-    float *row_loss = (float *)(ws + mp.off_rowloss);
+    const int nblocks = (int)ceil_div(b, 16);
+    unsigned *arrived = (unsigned *)(ws + mp.off_rowloss);                 // own 256-byte line
+    float *block_sum = (float *)(ws + mp.off_rowloss + 256);
+    sp.zero_word = arrived;
     ProfScope ps(MI_PROF_MOCO_FWD, 2.0 * (double)b * (double)(K + 1) * (double)D, s);
     HIP_CHECK((launch_sim<mi::DT_F32, mi::MODE_LSE>(sp, s)));
-    hipLaunchKernelGGL(moco_combine_kernel, dim3((unsigned)ceil_div(b, 16)), dim3(256), 0, s, q, key, (int)b, (int)D, sp.lse_part, mp.ntiles, mp.lse_ld, sp.inv_t, lse, lpos, row_loss);
-    HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, row_loss, (int)b, loss);
+    hipLaunchKernelGGL(moco_combine_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, q, key, (int)b, (int)D, sp.lse_part, mp.ntiles, mp.lse_ld, sp.inv_t, lse, lpos, block_sum, arrived, loss);
     HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

@@ -71,6 +71,10 @@ struct SimParams {
     float inv_t;
     float2 *lse_part;         // [ntiles, lse_ld] (max, sumexp) of every row over one tile; lse_ld = padded rows
     int lse_ld;
+    unsigned *zero_word;      // MODE_LSE: a word the NEXT kernel on the stream expects to be 0 (its arrival counter)
+    // STAMP instantiation only (diagnostic, mi_profile_clock): per workgroup (shader cycles, 100 MHz ticks) of its lifetime
+    unsigned long long *stamps;
+    int stamp_cap;            // entries (pairs) in `stamps`; workgroup b writes pair b % stamp_cap
 };
 
 // all-reduce over the 16 lanes of a DPP row (= one C-tile row of the 16x16 MFMA), no LDS traffic:
@@ -110,10 +114,14 @@ __device__ __forceinline__ float row16_sum(float v)
 #define MI_PF_POS 4
 #endif
 
-template <int DT, int MODE>
+template <int DT, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[SIM_LDS_BYTES + SIM_EXTRA_LDS];
+    // Diagnostic build of the same kernel (STAMP): the in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz.
+    // The stamps go to a buffer of their own; no output depends on them.  The production instantiation has none.
+    unsigned long long stamp_c0 = 0ull, stamp_r0 = 0ull;
+    if constexpr (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- block -> tile.  Blocks b and b+8 share an XCD (round-robin dispatch), an XCD holds 32
     // resident blocks (one per CU: 128 KiB LDS), so 32 consecutive same-XCD blocks form one patch
@@ -496,7 +504,16 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             // which tiles to look at, per row: a no-return atomic (nothing waits for it)
             if (n) atomicOr(p.tmask + (long long)(q0 + tid) * p.mask_words + (st >> 5), 1u << (st & 31));
         }
+        if constexpr (STAMP) {
+            if (tid == 0) {
+                const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+                unsigned long long *o = p.stamps + 2ll * (bid % p.stamp_cap);
+                o[0] = c1 - stamp_c0;
+                o[1] = r1 - stamp_r0;
+            }
+        }
     } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over the tile's 256 columns
+        if (bid == 0 && tid == 0 && p.zero_word) *p.zero_word = 0u;    // plain store: zero for the following kernel's atomics
         // Each wave reduces its 64 columns, the 4 column strips of a row meet in LDS (the operand
         // buffers are free after the K loop's last barrier) and the tile writes ONE contiguous
         // [256] float2 block.  (Per-strip 8-byte stores scattered over rows shared 128-byte lines

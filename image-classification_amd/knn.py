@@ -30,6 +30,10 @@ __all__ = ["knn_predict", "knn_predict_full", "knn_topk", "knn_topk_static", "kn
 # "bf16": inputs rounded to bfloat16, bf16 MFMA with float32 accumulation (the throughput mode).
 DEFAULT_COMPUTE_DTYPE = os.environ.get("MI_KNN_DTYPE", "fp32")
 
+# Candidate workspace of one fused top-k call (GiB).  The filter stages are sized by it (a stage's worst case -- every
+# similarity passing -- must fit), so more memory = fewer, larger stages = fewer threshold refreshes; 16 of the 288 GB.
+WORKSPACE_GIB = int(os.environ.get("MI_KNN_WORKSPACE_GIB", "16"))
+
 _DT = {"fp32": _lib.MI_F32, "f32": _lib.MI_F32, "float32": _lib.MI_F32,
        "bf16": _lib.MI_BF16, "bfloat16": _lib.MI_BF16}
 _TORCH_DT = {_lib.MI_F32: torch.float32, _lib.MI_BF16: torch.bfloat16}
@@ -190,7 +194,7 @@ def knn_topk(feature: torch.Tensor, bank: BankIndex, k: int) -> Tuple[torch.Tens
     L = _lib.lib()
     B = q.rows
     dev = feature.device
-    ws_bytes = int(L.mi_knn_topk_workspace_bytes(B, bank.n, k))
+    ws_bytes = int(L.mi_knn_topk_workspace_bytes_for_budget(B, bank.n, k, WORKSPACE_GIB << 30))
     if ws_bytes == 0:
         raise ValueError(f"unsupported kNN shape B={B} N={bank.n} k={k} (1 <= k <= {_lib.MI_MAX_K})")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -31,7 +31,7 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "chunk_bounds", "ShardedKnn", "QuerySlicedKnn", "HipOps"]
+__all__ = ["shard_bounds", "chunk_bounds", "auto_query_chunk", "ShardedKnn", "QuerySlicedKnn", "HipOps"]
 
 
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -50,6 +50,15 @@ def chunk_bounds(n: int, chunk: int):
     if len(lows) > 1 and n - lows[-1] < chunk // 4:
         lows.pop()
     return [(lo, lows[i + 1] if i + 1 < len(lows) else n) for i, lo in enumerate(lows)]
+
+
+def auto_query_chunk(n_local: int) -> int:
+    """Query rows per fused top-k call when the caller does not choose.  Every chunk pays one threshold bootstrap and
+    ramp (small, candidate-dense launches), while a larger chunk leaves fewer bank columns per stage in a given
+    candidate workspace.  Large shards need many stages and want them large (16 384-row chunks); a small shard is
+    done in a handful of stages whatever their size, so fewer, larger chunks win (measured on 1/2, 1/4 and 1/8 shards
+    of the 1.28 M-row bank: 16 384-row chunks are best down to 320 k rows, one 50 000-row chunk at 160 k)."""
+    return 16384 if n_local >= 240_000 else 65536
 
 
 class HipOps:
@@ -117,7 +126,7 @@ class ShardedKnn:
     """
 
     def __init__(self, bank_rows_local: torch.Tensor, idx_base: int, group=None, ops=None,
-                 compute_dtype=None, query_chunk: int = 8192, n_streams: int = 1, always_exchange: bool = False):
+                 compute_dtype=None, query_chunk: Optional[int] = 8192, n_streams: int = 1, always_exchange: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if _dist_on() else 1
         self.rank = dist.get_rank(group) if _dist_on() else 0
@@ -125,7 +134,7 @@ class ShardedKnn:
         self.idx_base = int(idx_base)
         self.bank = self.ops.build_bank(bank_rows_local, self.idx_base)
         self.n_local = int(self.ops.bank_rows(self.bank))
-        self.query_chunk = int(query_chunk)
+        self.query_chunk = int(query_chunk) if query_chunk else auto_query_chunk(self.n_local)      # None / 0: by shard size
         self.n_streams = max(1, int(n_streams))
         # always_exchange: a one-rank group still goes through the collectives and the merge (lets a one-GPU box
         # run the RCCL branches); otherwise a single rank skips them

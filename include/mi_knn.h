@@ -45,6 +45,12 @@ const char *mi_last_error(void);
 enum { MI_PROF_SIM = 0, MI_PROF_SELECT = 1, MI_PROF_MOCO_FWD = 2, MI_PROF_MOCO_BWD = 3 };
 int mi_profile_enable(int on);
 int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *total_work);
+/* Diagnostic: the shader clock the chip sustains inside the similarity kernel (MI355X lowers it under MFMA load).
+ * While a buffer is registered (device memory, `entries` pairs of uint64, 16-byte aligned), every filter launch of
+ * mi_knn_topk runs a stamped instantiation of the same kernel; workgroup b writes (shader cycles, 100 MHz ticks) of
+ * its lifetime to pair b % entries.  clock = cycles / ticks x 100 MHz (median over workgroups).  NULL switches it
+ * off.  Never on in a timed run: it is a separate build of the kernel.  Process-wide debug state behind a mutex. */
+int mi_profile_clock(void *stamps, int64_t entries);
 
 /* Leading dimension (in ELEMENTS of `dtype`) the similarity kernels require for a D-wide row:
  * D rounded up so that a row is a whole number of 128-byte K-steps (32 f32 / 64 bf16). */
@@ -73,6 +79,9 @@ int mi_bank_append_normalized(const float *src, int64_t ld_src, int64_t b, int64
  * larger workspace means fewer, larger stages; the minimum is the fixed part + B_pad*2048*8 bytes
  * (B_pad = B rounded up to 256).  The result never depends on the workspace size. */
 size_t mi_knn_topk_workspace_bytes(int64_t B, int64_t N, int k);
+/* The same for a candidate buffer of up to `candidate_bytes` instead of 8 GiB (never more than one stage over the
+ * whole bank needs): on a 288 GB part a caller with memory to spare buys fewer threshold refreshes with it. */
+size_t mi_knn_topk_workspace_bytes_for_budget(int64_t B, int64_t N, int k, size_t candidate_bytes);
 
 /* Fused similarity GEMM + streaming per-row top-k.  Replaces models/knn.py:6 (torch.mm) and
  * models/knn.py:8 (topk) without materialising the [B, N] similarity matrix.
