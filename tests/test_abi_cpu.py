@@ -53,6 +53,18 @@ def test_workspace_covers_worst_case_stage():
         assert ws >= b_pad * 2048 * 8
 
 
+def test_workspace_budget_is_monotone_and_capped():
+    """More candidate budget never shrinks the workspace, and it stops growing once one stage covers the bank."""
+    import image_classification_amd as ica
+    L = ica._lib.lib()
+    B, N, k = 16384, 1_280_000, 200
+    sizes = [L.mi_knn_topk_workspace_bytes_for_budget(B, N, k, g << 30) for g in (1, 8, 16, 64, 1024, 1 << 20)]
+    assert all(a <= b for a, b in zip(sizes, sizes[1:])) and sizes[-1] == sizes[-2]
+    assert sizes[1] == L.mi_knn_topk_workspace_bytes(B, N, k)
+    assert sizes[-1] >= 16384 * 1_280_000 * 8                      # the whole bank in one stage: worst case of every similarity passing
+    assert L.mi_knn_topk_workspace_bytes_for_budget(B, N, 2000, 8 << 30) == 0
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed():
     import torch
     import image_classification_amd as ica

@@ -185,6 +185,42 @@ def test_unwritten_query_rows_of_the_storage_bank(ica, dtype):
     assert np.all(np.isposinf(v.cpu().numpy())) and i.cpu().numpy().tolist() == [[0, 1, 2, 3, 4]]
 
 
+def test_result_does_not_depend_on_the_workspace_size(ica):
+    """mi_knn_topk sizes its filter stages by the workspace it is given (mi_knn.h): from the minimum (2048-column
+    stages) over the 8 GiB default to a budget that fits the whole bank in one stage, the stage schedule changes
+    completely and the result must not -- bit for bit, through the C ABI."""
+    f, x, _ = _rand_case(300, 40000, 64, 5, 123)
+    k = 200
+    bank = ica.BankIndex.from_rows(dev(x), "fp32")
+    q = ica.pack_rows(dev(f), False, "fp32")
+    L = ica._lib.lib()
+    b_pad = 512
+    minimum = int(L.mi_knn_topk_workspace_bytes_for_budget(300, 40000, k, 1))           # below the minimum -> the default plan
+    sizes = {
+        "tiny": b_pad * (8 + k * 8) + 64 * 1024 + b_pad * 2048 * 8 + b_pad * 40 + 8192,  # just above the documented minimum
+        "mid": int(L.mi_knn_topk_workspace_bytes_for_budget(300, 40000, k, 64 << 20)),
+        "default": int(L.mi_knn_topk_workspace_bytes(300, 40000, k)),
+        "one-stage": int(L.mi_knn_topk_workspace_bytes_for_budget(300, 40000, k, 1 << 40)),
+    }
+    assert minimum == sizes["default"] and sizes["tiny"] < sizes["mid"] <= sizes["default"] == sizes["one-stage"]
+    results = {}
+    for name, nbytes in sizes.items():
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        val = torch.empty((300, k), dtype=torch.float32, device="cuda")
+        idx = torch.empty((300, k), dtype=torch.int64, device="cuda")
+        ica._lib.check(L.mi_knn_topk(q.data.data_ptr(), q.ld, bank.packed.data.data_ptr(), bank.packed.ld, 0, 300, 40000, 64, k, 0,
+                                     val.data_ptr(), idx.data_ptr(), ws.data_ptr(), nbytes, ica._lib.stream_ptr(val.device)), name)
+        torch.cuda.synchronize()
+        results[name] = (val, idx)
+    v_ref, i_ref = chain.topk_rows(chain.sim_chain_f32(f, x), k)
+    for name, (val, idx) in results.items():
+        assert np.array_equal(val.cpu().numpy(), v_ref) and np.array_equal(idx.cpu().numpy(), i_ref), name
+    ws = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    rc = L.mi_knn_topk(q.data.data_ptr(), q.ld, bank.packed.data.data_ptr(), bank.packed.ld, 0, 300, 40000, 64, k, 0,
+                       val.data_ptr(), idx.data_ptr(), ws.data_ptr(), 4096, ica._lib.stream_ptr(val.device))
+    assert rc == -3 and b"below the minimum" in L.mi_last_error()
+
+
 def test_k_larger_than_n_raises_like_torch(ica):
     f, x, _ = _rand_case(4, 10, 32, 3, 0)
     with pytest.raises(RuntimeError, match="out of range"):

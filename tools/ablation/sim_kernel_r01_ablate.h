@@ -1,12 +1,18 @@
+// BENCH-ONLY COPY -- never built into libmi_knn.so, not maintained.
+// The round-1 similarity kernel with its MI_ABLATE timing-only variants: several of them are DATA
+// RACES or skip work on purpose (no K-step barrier, DMA left in flight, no epilogue) and produce wrong results; they
+// exist to price parts of the loop, not to run.  The product kernel (image-classification_amd/csrc/sim_kernel.h)
+// carries none of them and no hook for them.  To re-run a variant, check out the tree the numbers were taken on
+// (commit 775728b, where this file is image-classification_amd/csrc/sim_kernel.h) and build
+//     tools/build_variant.sh abl16 -DMI_ABLATE=16
+// there; run it with MI_KNN_LIB=.../libmi_knn_abl16.so python bench.py --no-cpu-baseline.
 // sim_kernel.h -- fused similarity GEMM tile + streaming top-k filter for gfx950 (CDNA4).
 //
 // One workgroup (512 threads = 8 waves, one per CU) computes a 256 x 256 tile of
 //     sim[b][n] = sum_k q[b][k] * bank[n][k]                       (models/knn.py:6)
 // with MFMA and never writes it to HBM.  What leaves the tile depends on MODE:
 //   MODE_DENSE  : bootstrap stage -- the tile is stored densely (values only) into the per-row
-//                 candidate buffer, the select kernel turns it into the first threshold (a strided
-//                 sample of the bank: dense column c = bank row c * row_stride) or, for a bank no
-//                 larger than the bootstrap, into the final top-k;
+//                 candidate buffer, the select kernel turns it into the first top-k + threshold;
 //   MODE_FILTER : every element is compared with its row's threshold tau[row] (a lower bound of
 //                 the row's final k-th largest similarity); survivors (rare) go straight to the
 //                 (row, bank tile) segment of the row's candidate buffer in HBM -- slot from an LDS
@@ -56,7 +62,6 @@ struct SimParams {
     int ksteps;               // padded row bytes / 128
     int col0, ncols;          // this launch covers bank rows [col0, col0 + ncols)
     int nt_base;              // MODE_FILTER: stage tile of the launch's tile 0 (a stage may take several launches)
-    int row_stride;           // MODE_DENSE: dense column c is bank row c * row_stride (strided sample of the bank)
     int qtiles, ntiles;       // tiles in this launch
     int pq, pn, qsh;          // patches of (1 << qsh) query tiles x (32 >> qsh) bank tiles (set by the launcher)
     // MODE_DENSE / MODE_FILTER
@@ -71,10 +76,6 @@ struct SimParams {
     float inv_t;
     float2 *lse_part;         // [ntiles, lse_ld] (max, sumexp) of every row over one tile; lse_ld = padded rows
     int lse_ld;
-    unsigned *zero_word;      // MODE_LSE: a word the NEXT kernel on the stream expects to be 0 (its arrival counter)
-    // STAMP instantiation only (diagnostic, mi_profile_clock): per workgroup (shader cycles, 100 MHz ticks) of its lifetime
-    unsigned long long *stamps;
-    int stamp_cap;            // entries (pairs) in `stamps`; workgroup b writes pair b % stamp_cap
 };
 
 // all-reduce over the 16 lanes of a DPP row (= one C-tile row of the 16x16 MFMA), no LDS traffic:
@@ -101,6 +102,9 @@ __device__ __forceinline__ float row16_sum(float v)
 
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
+#ifndef MI_DMA_SHIFT
+#define MI_DMA_SHIFT 0
+#endif
 #ifndef MI_L2_PREFETCH
 #define MI_L2_PREFETCH 1
 #endif
@@ -111,14 +115,10 @@ __device__ __forceinline__ float row16_sum(float v)
 #define MI_PF_POS 4
 #endif
 
-template <int DT, int MODE, bool STAMP = false>
+template <int DT, int MODE>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[SIM_LDS_BYTES + SIM_EXTRA_LDS];
-    // Diagnostic build of the same kernel (STAMP): the in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz.
-    // The stamps go to a buffer of their own; no output depends on them.  The production instantiation has none.
-    unsigned long long stamp_c0 = 0ull, stamp_r0 = 0ull;
-    if constexpr (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- block -> tile.  Blocks b and b+8 share an XCD (round-robin dispatch), an XCD holds 32
     // resident blocks (one per CU: 128 KiB LDS), so 32 consecutive same-XCD blocks form one patch
@@ -148,12 +148,13 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         const int r = (w * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         int qa = q0 + r; qa = qa < p.B ? qa : p.B - 1;             // clamp: padding rows re-read a valid row
-        int xb = n0 + r;
-        if constexpr (MODE == MODE_DENSE) {                          // padding columns re-read the last sampled row
-            xb = xb < col_end ? xb : col_end - 1;
-            xb *= p.row_stride;                                      // < N: (s0 - 1) * floor(N / s0)
-        }
-        xb = xb < p.N ? xb : p.N - 1;
+        int xb = n0 + r; xb = xb < p.N ? xb : p.N - 1;
+#if defined(MI_ABLATE) && (MI_ABLATE & 1)
+        xb = r;                                                      // timing-only: bank tile 0 for everyone
+#endif
+#if defined(MI_ABLATE) && (MI_ABLATE & 4)
+        qa = r;                                                      // timing-only: query tile 0 for everyone
+#endif
         a_src[i] = p.q + (long long)qa * p.ldq_bytes + chunk * 16;
         b_src[i] = p.x + (long long)xb * p.ldx_bytes + chunk * 16;
     }
@@ -166,6 +167,31 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         const unsigned base = (unsigned)(size_t)(AS3 char *)(smem + buf * STAGE_BYTES + w * 4096 + i * 1024);
         const long long koff = (long long)t * KSTEP_BYTES;
         unsigned keep;
+#if defined(MI_ABLATE) && (MI_ABLATE & 64)
+        {   // timing-only: the DMA instructions issue with EXEC = 0 (no memory traffic at all)
+            unsigned long long ex;
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\ts_mov_b64 %[ex], exec\n\ts_mov_b64 exec, 0\n\t"
+                "s_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a], off\n\t"
+                "s_mov_b32 m0, %[lb]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b], off\n\t"
+                "s_mov_b32 m0, %[keep]\n\ts_mov_b64 exec, %[ex]"
+                : [keep] "=&s"(keep), [ex] "=&s"(ex)
+                : [la] "s"(base), [lb] "s"(base + OPERAND_TILE_BYTES), [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
+                : "memory");
+            return;
+        }
+#endif
+#if defined(MI_ABLATE) && (MI_ABLATE & 128)
+        {   // timing-only: same global traffic, but into (discarded) registers instead of LDS
+            f32x4 d0, d1;
+            asm volatile(
+                "global_load_dwordx4 %[d0], %[a], off\n\tglobal_load_dwordx4 %[d1], %[b], off"
+                : [d0] "=&v"(d0), [d1] "=&v"(d1)
+                : [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
+                : "memory");
+            return;
+        }
+#endif
         asm volatile(
             "s_mov_b32 %[keep], m0\n\t"
             "s_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a], off\n\t"
@@ -175,11 +201,15 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             : [la] "s"(base), [lb] "s"(base + OPERAND_TILE_BYTES), [a] "v"(a_src[i] + koff), [b] "v"(b_src[i] + koff)
             : "memory");
     };
+#if defined(MI_ABLATE) && (MI_ABLATE & 16)
+    auto stage_wait = [&](auto) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); };   // timing-only: one K-step of DMA stays in flight
+#else
     // vmcnt counts in issue order: with a prefetch issued after the K-step's DMA, vmcnt(1) waits for the DMA only
     auto stage_wait = [&](auto pf_tag) {
         if constexpr (decltype(pf_tag)::value) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+#endif
 
 #if MI_L2_PREFETCH
     // ---- L2 prefetch.  The 32 workgroups of an XCD patch stream the same 8 + 4 operand tiles, so 19 % of the
@@ -198,12 +228,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             int r = q0 + la * (inner >> p.qsh) + idx; r = r < p.B ? r : p.B - 1;
             pf_src = p.q + (long long)r * p.ldq_bytes;
         } else {
-            int r = n0 + lb * (inner & ((1 << p.qsh) - 1)) + (idx - la);
-            if constexpr (MODE == MODE_DENSE) {
-                r = r < col_end ? r : col_end - 1;
-                r *= p.row_stride;
-            }
-            r = r < p.N ? r : p.N - 1;
+            int r = n0 + lb * (inner & ((1 << p.qsh) - 1)) + (idx - la); r = r < p.N ? r : p.N - 1;
             pf_src = p.x + (long long)r * p.ldx_bytes;
         }
     }
@@ -270,7 +295,13 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 bf16x8 *ac = (pr & 1) ? a1 : a0, *an = (pr & 1) ? a0 : a1;
                 bf16x8 *bc = s ? b1 : b0;
                 if constexpr (DMA) {
+#if MI_DMA_SHIFT == 0
                     if (pr < 4) stage_pair(pr, t + 1, nbuf);
+#else
+                    // the two waves of a SIMD (w, w + 4) issue their pieces MI_DMA_SHIFT groups apart
+                    if (pr < 4) { if (w < 4) stage_pair(pr, t + 1, nbuf); }
+                    if (pr >= MI_DMA_SHIFT && pr < MI_DMA_SHIFT + 4) { if (w >= 4) stage_pair(pr - MI_DMA_SHIFT, t + 1, nbuf); }
+#endif
                 }
                 if constexpr (PF) {
                     if (pr == MI_PF_POS) prefetch(t + MI_PF_DIST);
@@ -278,11 +309,23 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 if (pr < 7) {
                     const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;
                     const int co = ns ? coff1 : coff0;
+#if defined(MI_ABLATE) && (MI_ABLATE & 256)
+                    if (ns) {                           // timing-only: half the operand reads (K-half 1 reuses registers)
+                        an[0] = ac[1];
+                        an[1] = ac[0];
+                        if (pr == 3) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) b1[j] = b0[3 - j];
+                        }
+                    } else
+#endif
+                    {
                     an[0] = *(const bf16x8 *)(la + (2 * np) * 2048 + co);
                     an[1] = *(const bf16x8 *)(la + (2 * np + 1) * 2048 + co);
                     if (pr == 3) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) b1[j] = *(const bf16x8 *)(lb + j * 2048 + coff1);
+                    }
                     }
                 }
 #pragma unroll
@@ -346,7 +389,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             MI_MM(32);
         }
         stage_wait(pf_tag);
-        __syncthreads();
+#if !(defined(MI_ABLATE) && (MI_ABLATE & 512))
+        __syncthreads();                                            // (ablation 512, timing only: no K-step barrier)
+#endif
     };
 #undef MI_RD
 #undef MI_MM
@@ -355,7 +400,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     for (int i = 0; i < 4; ++i) stage_pair(i, 0, 0);
     stage_wait(std::false_type{});
     __syncthreads();
-#if MI_L2_PREFETCH
+#if defined(MI_ABLATE) && (MI_ABLATE & 2)
+    for (int t = 0; t < p.ksteps; ++t) kstep(t, std::false_type{}, std::false_type{});          // timing-only: no DMA in the loop
+#elif MI_L2_PREFETCH
     for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{});
     if (p.ksteps > 1) kstep(p.ksteps - 2, std::true_type{}, std::false_type{});
     kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
@@ -385,6 +432,19 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 }
             }
     } else if constexpr (MODE == MODE_FILTER) {
+#if defined(MI_ABLATE) && (MI_ABLATE & 8)
+        {   // timing-only: keep the accumulators live, emit (almost) nothing
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
+            if (sum == 12345.678f) p.cnt2[0] = 1;
+            return;
+        }
+#endif
         // Survivors go straight to HBM with NO global atomic: bank tile nt owns slots [256 nt, 256 nt + 256) of
         // every row's candidate list (cap >= the stage's columns, so the segment always exists and can never
         // overflow), an LDS atomic hands out the slot inside the segment, and the tile ends by storing its 256
@@ -420,6 +480,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     }
                 }
             }
+#if defined(MI_ABLATE) && (MI_ABLATE & 1024)
+        return;                                                     // timing-only: no per-tile counts
+#endif
         __syncthreads();
         if (tid < TILE) {
             const unsigned n = lcnt[tid];
@@ -428,21 +491,25 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             // which tiles to look at, per row: a no-return atomic (nothing waits for it)
             if (n) atomicOr(p.tmask + (long long)(q0 + tid) * p.mask_words + (st >> 5), 1u << (st & 31));
         }
-        if constexpr (STAMP) {
-            if (tid == 0) {
-                const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-                unsigned long long *o = p.stamps + 2ll * (bid % p.stamp_cap);
-                o[0] = c1 - stamp_c0;
-                o[1] = r1 - stamp_r0;
-            }
-        }
     } else {   // MODE_LSE: per-row (max, sum exp) of sim * inv_t over the tile's 256 columns
-        if (bid == 0 && tid == 0 && p.zero_word) *p.zero_word = 0u;    // plain store: zero for the following kernel's atomics
         // Each wave reduces its 64 columns, the 4 column strips of a row meet in LDS (the operand
         // buffers are free after the K loop's last barrier) and the tile writes ONE contiguous
         // [256] float2 block.  (Per-strip 8-byte stores scattered over rows shared 128-byte lines
         // between workgroups of different XCDs: 262k partial-line writes cost 150 us at C2.)
         float2 *lpart = (float2 *)smem;                               // [256 rows][4 strips]
+#if defined(MI_ABLATE) && (MI_ABLATE & 32)
+        {   // timing-only: no reduction work
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
+            if (sum == 12345.678f) p.lse_part[0] = make_float2(sum, sum);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
