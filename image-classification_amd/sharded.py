@@ -57,8 +57,8 @@ def auto_query_chunk(n_local: int) -> int:
     ramp (small, candidate-dense launches), while a larger chunk leaves fewer bank columns per stage in a given
     candidate workspace.  Large shards need many stages and want them large (16 384-row chunks); a small shard is
     done in a handful of stages whatever their size, so fewer, larger chunks win (measured on 1/2, 1/4 and 1/8 shards
-    of the 1.28 M-row bank: 16 384-row chunks are best down to 320 k rows, one 50 000-row chunk at 160 k)."""
-    return 16384 if n_local >= 240_000 else 65536
+    of the 1.28 M-row bank: 16 384-row chunks are best at 640 k rows, one 50 000-row chunk at 320 k and 160 k)."""
+    return 16384 if n_local >= 480_000 else 65536
 
 
 class HipOps:
