@@ -211,7 +211,7 @@ def main():
     # give-back item 6): two more untimed steps through the STAMPED instantiation of the same kernel, right after
     # the timed region; clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the workgroups.
     clock_ghz = None
-    if rank == 0 and not args.no_clock_probe:
+    if not args.no_clock_probe:                      # every rank: the probe steps contain the job's collectives
         stamps = torch.zeros((16384, 2), dtype=torch.int64, device=device)
         _lib.check(_lib.lib().mi_profile_clock(stamps.data_ptr(), stamps.shape[0]), "mi_profile_clock")
         try:

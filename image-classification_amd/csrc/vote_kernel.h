@@ -136,29 +136,63 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(const VoteParams p)
 //      vote follow in ascending order, placed by ballot prefix over an LDS class -> bin map (which also serves the
 //      optional dense score row).
 // HBM traffic is the algorithmic minimum (k * 12 B in, classes * 8 (+4) B out per row); 16+ rows are in flight per CU.
-constexpr int VOTE_WAVE_MAX_C = 2048;          // 4 waves x (5 KiB + 2 B per class) stay below 48 KiB of dynamic LDS
+constexpr int VOTE_WAVE_MAX_C = 2048;          // 4 waves x (3 KiB + 2 B per class) stay well below 48 KiB of dynamic LDS
+
+// Bitonic sort of 256 keys held by one wave in REGISTERS, 4 per lane (sorted position i = 4 * lane + s): the two
+// innermost strides of every merge step are register-to-register inside a lane, the others fetch the partner lane's
+// key with one cross-lane read each (lane ^ 1, 2: DPP quad_perm; lane ^ 4 .. 32: ds_bpermute, which uses the LDS
+// crossbar but no LDS memory).  36 compare-exchange layers, fully unrolled; no LDS traffic, no barrier.
+template <typename T> __device__ __forceinline__ T lane_xor(T v, int m);
+template <> __device__ __forceinline__ unsigned lane_xor<unsigned>(unsigned v, int m)
+{
+    if (m == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    if (m == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    return (unsigned)__shfl_xor((int)v, m, 64);
+}
+template <> __device__ __forceinline__ unsigned long long lane_xor<unsigned long long>(unsigned long long v, int m)
+{
+    const unsigned lo = lane_xor<unsigned>((unsigned)v, m), hi = lane_xor<unsigned>((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 template <typename T, bool DESC>
-__device__ __forceinline__ void wave_bitonic_sort(T *keys, int n, int lane)
+__device__ __forceinline__ void wave_sort256(T (&k)[4], int lane)
 {
-    for (int size = 2; size <= n; size <<= 1) {
+#pragma unroll
+    for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = lane; t < (n >> 1); t += 64) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool first_big = ((lo & size) == 0) == DESC;     // the larger key belongs at `lo`
-                const T a = keys[lo], b = keys[hi];
-                if ((a < b) == first_big) { keys[lo] = b; keys[hi] = a; }
+            if (stride >= 4) {
+                const int m = stride >> 2;
+                const bool lower = (lane & m) == 0;
+                const bool up = (size == 256) || ((lane & (size >> 2)) == 0);       // this block sorts towards the final order
+                const bool keep_first = (lower == up);                                // keep the key that comes first in the final order
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const T o = lane_xor<T>(k[s2], m);
+                    const bool o_first = DESC ? (o > k[s2]) : (o < k[s2]);            // the partner's key comes first
+                    k[s2] = (o_first == keep_first) ? o : k[s2];
+                }
+            } else {
+#pragma unroll
+                for (int lo = 0; lo < 4; ++lo) {
+                    if (lo & stride) continue;
+                    const int hi = lo | stride;
+                    const bool up = (size >= 4) ? ((size == 256) || ((lane & (size >> 2)) == 0)) : ((lo & size) == 0);
+                    const T a = k[lo], b = k[hi];
+                    const bool b_first = DESC ? (b > a) : (b < a);
+                    const bool swap = (b_first == up);
+                    k[lo] = swap ? b : a;
+                    k[hi] = swap ? a : b;
+                }
             }
-            wave_step();
         }
     }
 }
 
 inline size_t vote_wave_lds_bytes(int classes)
 {
-    const size_t per_wave = 256 * 4 /*w*/ + 256 * 4 /*label keys*/ + 256 * 4 /*bin totals*/ + 256 * 8 /*bin keys*/
-                          + (size_t)((classes * 2 + 15) / 16 * 16);
+    const size_t per_wave = 256 * 4 /*w*/ + 256 * 4 /*label keys*/ + 256 * 4 /*bin totals*/ + (size_t)((classes * 2 + 15) / 16 * 16);
     return 4 * per_wave;
 }
 
@@ -169,62 +203,70 @@ __global__ __launch_bounds__(256) void vote_wave_kernel(const VoteParams p)
     const long long row = (long long)blockIdx.x * 4 + wv;
     if (row >= p.B) return;
     const int k = p.k, C = p.classes;
-    const size_t per_wave = 256 * 4 * 3 + 256 * 8 + (size_t)((C * 2 + 15) / 16 * 16);
+    const size_t per_wave = 256 * 4 * 3 + (size_t)((C * 2 + 15) / 16 * 16);
     unsigned char *base = dyn + wv * per_wave;
-    unsigned long long *s_bin = (unsigned long long *)base;            // [256] (total, class) keys of the bins
-    float *s_w = (float *)(base + 2048);                               // [256] weight of neighbour j
-    unsigned *s_lk = (unsigned *)(base + 3072);                        // [256] label << 8 | j
-    float *s_tot = (float *)(base + 4096);                             // [256] bin totals (by bin number before the sort)
-    unsigned short *slot = (unsigned short *)(base + 5120);            // [C] class -> bin + 1 (0: no vote)
+    float *s_w = (float *)base;                                        // [256] weight of neighbour j
+    unsigned *s_lk = (unsigned *)(base + 1024);                        // [256] sorted label << 8 | j
+    float *s_tot = (float *)(base + 2048);                             // [256] bin totals (by bin number before the sort)
+    unsigned short *slot = (unsigned short *)(base + 3072);            // [C] class -> bin + 1 (0: no vote)
 
-    int n2 = 64;
-    while (n2 < k) n2 <<= 1;
-    // (knn.py:10-11) gather labels, w = exp(sim / T): division first, then exp, as the reference
-    for (int j = lane; j < n2; j += 64) {
-        unsigned key = 0xFFFFFFFFu;
-        float w = 0.f;
-        if (j < k) {
-            const long long i = p.idx[row * k + j];
-            if (i >= 0 && i < p.n_labels) {
-                const long long ll = p.labels[i];
-                if (ll >= 0 && ll < C) { key = ((unsigned)ll << 8) | (unsigned)j; w = expf(p.val[row * k + j] / p.knn_t); }
-            }
-        }
-        s_lk[j] = key;
-        s_w[j] = w;
+    // (knn.py:10-11) gather labels, w = exp(sim / T): division first, then exp, as the reference.
+    // All index loads first, then all label loads, then the values: one round trip each, not four.
+    long long bi[4];
+    float sv[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const int j = s2 * 64 + lane;
+        bi[s2] = j < k ? p.idx[row * k + j] : -1ll;
+        sv[s2] = j < k ? p.val[row * k + j] : 0.f;
     }
+    long long bl[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) bl[s2] = (bi[s2] >= 0 && bi[s2] < p.n_labels) ? p.labels[bi[s2]] : -1ll;
     for (int c = lane; c < C; c += 64) slot[c] = 0;
+    unsigned lk[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const int j = s2 * 64 + lane;
+        const bool ok = bl[s2] >= 0 && bl[s2] < C;
+        lk[s2] = ok ? (((unsigned)bl[s2] << 8) | (unsigned)j) : 0xFFFFFFFFu;
+        s_w[j] = ok ? expf(sv[s2] / p.knn_t) : 0.f;
+    }
+    wave_sort256<unsigned, false>(lk, lane);                           // runs of equal label, neighbour rank ascending
+    *(uint4 *)(s_lk + 4 * lane) = make_uint4(lk[0], lk[1], lk[2], lk[3]);
     wave_step();
-    wave_bitonic_sort<unsigned, false>(s_lk, n2, lane);                // runs of equal label, neighbour rank ascending
 
     // (knn.py:14-18) one histogram bin per run, summed in ascending neighbour rank
+    unsigned long long bk[4];
     int nbins = 0;
-    for (int t0 = 0; t0 < n2; t0 += 64) {
-        const int t = t0 + lane;
-        const unsigned key = s_lk[t];
+    const unsigned prev_lane_last = lane ? s_lk[4 * lane - 1] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const int t = 4 * lane + s2;
+        const unsigned key = lk[s2];
         const unsigned l = key >> 8;
-        const bool head = key != 0xFFFFFFFFu && (t == 0 || (s_lk[t - 1] >> 8) != l);
+        const unsigned before = s2 ? lk[s2 ? s2 - 1 : 0] : prev_lane_last;
+        const bool head = key != 0xFFFFFFFFu && (t == 0 || (before >> 8) != l);
         float sum = 0.f;
         if (head)
-            for (int u = t; u < n2 && (s_lk[u] >> 8) == l; ++u) sum += s_w[s_lk[u] & 255u];
+            for (int u = t; u < 256 && (s_lk[u] >> 8) == l; ++u) sum += s_w[s_lk[u] & 255u];
         const unsigned long long bal = __ballot(head);
+        bk[s2] = 0ull;
         if (head) {
             const int b = nbins + __popcll(bal & ((1ull << lane) - 1ull));
             s_tot[b] = sum;
             slot[l] = (unsigned short)(b + 1);
-            s_bin[b] = ((unsigned long long)orderable_f32(sum) << 32) | (unsigned long long)(0xFFFFFFFFu - l);
+            bk[s2] = ((unsigned long long)orderable_f32(sum) << 32) | (unsigned long long)(0xFFFFFFFFu - l);
         }
         nbins += __popcll(bal);
     }
-    int m2 = 64;
-    while (m2 < nbins) m2 <<= 1;
-    wave_step();
-    for (int i = nbins + lane; i < m2; i += 64) s_bin[i] = 0ull;
-    wave_step();
-    // (knn.py:20) ranking: voted classes by (total desc, class asc) ...
-    wave_bitonic_sort<unsigned long long, true>(s_bin, m2, lane);
+    // (knn.py:20) ranking: voted classes by (total desc, class asc): empty slots (0) sort behind every bin ...
+    wave_sort256<unsigned long long, true>(bk, lane);
     long long *rank = p.out_rank + row * C;
-    for (int i = lane; i < nbins; i += 64) rank[i] = (long long)(0xFFFFFFFFu - (unsigned)s_bin[i]);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+        if (4 * lane + s2 < nbins) rank[4 * lane + s2] = (long long)(0xFFFFFFFFu - (unsigned)bk[s2]);
+    wave_step();
     // ... followed by every class without a vote, ascending; the dense score row on the way
     int running = nbins;
     for (int c0 = 0; c0 < C; c0 += 64) {

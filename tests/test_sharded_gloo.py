@@ -77,7 +77,7 @@ def test_shard_bounds_cover_everything():
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_knn_gloo_cpu(world):
     outs, ref = _run(world, "cpu")
     _check(outs, ref, exact_values=False)
