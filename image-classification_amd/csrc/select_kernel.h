@@ -759,6 +759,58 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
     }
 }
 
+// Bitonic sort of 256 keys held by one wave in REGISTERS, 4 per lane (sorted position i = 4 * lane + s): the two
+// innermost strides of every merge step are register-to-register inside a lane, the others fetch the partner lane's
+// key with one cross-lane read each (lane ^ 1, 2: DPP quad_perm; lane ^ 4 .. 32: ds_bpermute, which uses the LDS
+// crossbar but no LDS memory).  36 compare-exchange layers, fully unrolled; no LDS traffic, no barrier.
+template <typename T> __device__ __forceinline__ T lane_xor(T v, int m);
+template <> __device__ __forceinline__ unsigned lane_xor<unsigned>(unsigned v, int m)
+{
+    if (m == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    if (m == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    return (unsigned)__shfl_xor((int)v, m, 64);
+}
+template <> __device__ __forceinline__ unsigned long long lane_xor<unsigned long long>(unsigned long long v, int m)
+{
+    const unsigned lo = lane_xor<unsigned>((unsigned)v, m), hi = lane_xor<unsigned>((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename T, bool DESC>
+__device__ __forceinline__ void wave_sort256(T (&k)[4], int lane)
+{
+#pragma unroll
+    for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 4) {
+                const int m = stride >> 2;
+                const bool lower = (lane & m) == 0;
+                const bool up = (size == 256) || ((lane & (size >> 2)) == 0);       // this block sorts towards the final order
+                const bool keep_first = (lower == up);                                // keep the key that comes first in the final order
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const T o = lane_xor<T>(k[s2], m);
+                    const bool o_first = DESC ? (o > k[s2]) : (o < k[s2]);            // the partner's key comes first
+                    k[s2] = (o_first == keep_first) ? o : k[s2];
+                }
+            } else {
+#pragma unroll
+                for (int lo = 0; lo < 4; ++lo) {
+                    if (lo & stride) continue;
+                    const int hi = lo | stride;
+                    const bool up = (size >= 4) ? ((size == 256) || ((lane & (size >> 2)) == 0)) : ((lo & size) == 0);
+                    const T a = k[lo], b = k[hi];
+                    const bool b_first = DESC ? (b > a) : (b < a);
+                    const bool swap = (b_first == up);
+                    k[lo] = swap ? b : a;
+                    k[hi] = swap ? a : b;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register-resident threshold refresh (k <= 256): ONE wave folds ONE query row's new candidates into
 // the row's kept keys and raises its threshold -- the stage refresh of the filter scheme.
@@ -777,7 +829,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const SelectParams p)
 //     all, stopping when one key is left (about log2(keys) + a few steps); keys that drop out are zeroed in
 //     a working copy, so no activity mask is carried; no LDS histogram, no atomics, no barrier;
 //   * the survivors (exactly k: keys are distinct) are compacted through 2 KiB of wave-private LDS back into
-//     the bag; the final stage sorts that LDS copy (bitonic, wave-private) and emits (value, index).
+//     the bag; the final stage sorts the bag once, in registers (wave_sort256), and emits (value, index).
 // This replaces the counting merge + LDS radix-select/compact/sort pair for k <= 256; k > 256 keeps the
 // workgroup-per-row kernels above.
 constexpr int BAG_WIN = 512;           // bank tiles per prefix window (2 KiB of LDS per wave)
@@ -923,8 +975,13 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const SelectParams p)
             const unsigned x = (f[u] != f[u]) ? 0u : orderable_f32(f[u]);             // NaN: not a candidate
             w[4 * j + u] = x;
             if (x) { a &= x; o |= x; }
-            nz += __popcll(__ballot(x != 0u));
+            nz += x != 0u;                                      // per lane; summed over the wave below
         }
+    }
+    {
+        int total;
+        (void)wave_scan_incl(nz, lane, total);
+        nz = total;
     }
     if (nz < p.k) return;                                       // tau stays -inf
     a = wave_and_u32(a);
@@ -1075,19 +1132,19 @@ __global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams 
     }
     if (finalize) {
         if (!have_bag) load_bag();
-        int n2 = 64;
-        while (n2 < n_cur) n2 <<= 1;
-        wave_step();
+        // the one sort of the row: the bag's keys through the register sorting network (empty slots, 0, go last)
+        unsigned long long k4[4];
 #pragma unroll
-        for (int j = 0; j < KPL; ++j)
-            if (j * 64 < n2) sm.bag[j * 64 + lane] = key[j];                // zeros pad up to n2
-        wave_step();
-        wave_bitonic_sort_desc(sm.bag, n2, lane);
-        for (int i = lane; i < k; i += 64) {
-            const bool ok = i < n_cur;
-            const unsigned long long kk = ok ? sm.bag[i] : 0ull;
-            p.out_val[row * k + i] = ok ? key_value(kk) : -INFINITY;
-            p.out_idx[row * k + i] = ok ? p.idx_base + (long long)key_row(kk) : -1ll;
+        for (int j = 0; j < 4; ++j) k4[j] = j < KPL ? key[j < KPL ? j : 0] : 0ull;
+        wave_sort256<unsigned long long, true>(k4, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * lane + j;                                     // sorted position
+            if (i < k) {
+                const bool ok = i < n_cur;
+                p.out_val[row * k + i] = ok ? key_value(k4[j]) : -INFINITY;
+                p.out_idx[row * k + i] = ok ? p.idx_base + (long long)key_row(k4[j]) : -1ll;
+            }
         }
     }
 }

@@ -138,58 +138,6 @@ __global__ __launch_bounds__(VOTE_THREADS) void vote_kernel(const VoteParams p)
 // HBM traffic is the algorithmic minimum (k * 12 B in, classes * 8 (+4) B out per row); 16+ rows are in flight per CU.
 constexpr int VOTE_WAVE_MAX_C = 2048;          // 4 waves x (3 KiB + 2 B per class) stay well below 48 KiB of dynamic LDS
 
-// Bitonic sort of 256 keys held by one wave in REGISTERS, 4 per lane (sorted position i = 4 * lane + s): the two
-// innermost strides of every merge step are register-to-register inside a lane, the others fetch the partner lane's
-// key with one cross-lane read each (lane ^ 1, 2: DPP quad_perm; lane ^ 4 .. 32: ds_bpermute, which uses the LDS
-// crossbar but no LDS memory).  36 compare-exchange layers, fully unrolled; no LDS traffic, no barrier.
-template <typename T> __device__ __forceinline__ T lane_xor(T v, int m);
-template <> __device__ __forceinline__ unsigned lane_xor<unsigned>(unsigned v, int m)
-{
-    if (m == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
-    if (m == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
-    return (unsigned)__shfl_xor((int)v, m, 64);
-}
-template <> __device__ __forceinline__ unsigned long long lane_xor<unsigned long long>(unsigned long long v, int m)
-{
-    const unsigned lo = lane_xor<unsigned>((unsigned)v, m), hi = lane_xor<unsigned>((unsigned)(v >> 32), m);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-template <typename T, bool DESC>
-__device__ __forceinline__ void wave_sort256(T (&k)[4], int lane)
-{
-#pragma unroll
-    for (int size = 2; size <= 256; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride >= 4) {
-                const int m = stride >> 2;
-                const bool lower = (lane & m) == 0;
-                const bool up = (size == 256) || ((lane & (size >> 2)) == 0);       // this block sorts towards the final order
-                const bool keep_first = (lower == up);                                // keep the key that comes first in the final order
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    const T o = lane_xor<T>(k[s2], m);
-                    const bool o_first = DESC ? (o > k[s2]) : (o < k[s2]);            // the partner's key comes first
-                    k[s2] = (o_first == keep_first) ? o : k[s2];
-                }
-            } else {
-#pragma unroll
-                for (int lo = 0; lo < 4; ++lo) {
-                    if (lo & stride) continue;
-                    const int hi = lo | stride;
-                    const bool up = (size >= 4) ? ((size == 256) || ((lane & (size >> 2)) == 0)) : ((lo & size) == 0);
-                    const T a = k[lo], b = k[hi];
-                    const bool b_first = DESC ? (b > a) : (b < a);
-                    const bool swap = (b_first == up);
-                    k[lo] = swap ? b : a;
-                    k[hi] = swap ? a : b;
-                }
-            }
-        }
-    }
-}
-
 inline size_t vote_wave_lds_bytes(int classes)
 {
     const size_t per_wave = 256 * 4 /*w*/ + 256 * 4 /*label keys*/ + 256 * 4 /*bin totals*/ + (size_t)((classes * 2 + 15) / 16 * 16);
