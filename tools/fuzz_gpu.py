@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised shape fuzz of mi_knn_topk (fp32, bit-exact vs the chain oracle) and of the bf16 mode (vs the bf16-rounded
-chain) on one GPU.  usage: tools/fuzz_gpu.py [cases] [seed]"""
+"""Randomised shape fuzz on one GPU: mi_knn_topk (fp32, bit-exact vs the chain oracle; clustered cases also with the
+bank sorted so that a query meets all its neighbours in one stage) and mi_knn_vote on the result under random labels
+(scores within 1e-5, ranking a permutation, descending, ties to the lower class).  usage: tools/fuzz_gpu.py [cases] [seed]"""
 import os
 import sys
 import time
@@ -41,7 +42,27 @@ for c in range(cases):
     v_ref, i_ref = chain.topk_rows(sim, k)
     v, i = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(x).cuda(), "fp32"), k)
     ok = np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+    # sorted banks: every query meets all its neighbours in one stage (class-ordered memo loader)
+    if ok and style == "clustered" and N > 4096:
+        order = np.argsort(-(x @ x[0]), kind="stable")
+        xs = np.ascontiguousarray(x[order])
+        v_ref2, i_ref2 = chain.topk_rows(chain.sim_chain_f32(f, xs), k)
+        v2, i2 = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(xs).cuda(), "fp32"), k)
+        ok = np.array_equal(v2.cpu().numpy(), v_ref2) and np.array_equal(i2.cpu().numpy(), i_ref2)
+    # vote + ranking of this case's neighbours under random labels (wave-per-row kernel for k <= 256, C <= 2048)
+    if ok:
+        C = int(rs.choice([1, 2, 10, 100, 1000, 2048, 5000]))
+        lab = rs.randint(0, C, size=N)
+        rank, scores = ica.knn_vote(v, i, torch.from_numpy(lab).cuda(), C, 0.1, return_scores=True)
+        s_ref = ko.vote_scores(ko.vote_weights(v_ref, 0.1), lab[i_ref], C)
+        sc, rk = scores.cpu().numpy(), rank.cpu().numpy()
+        ok = bool(np.all(np.isclose(sc, s_ref, rtol=1e-5, atol=1e-30)))            # inf == inf (unnormalised 'ascending' rows overflow exp)
+        ok = ok and np.array_equal(np.sort(rk, axis=1), np.tile(np.arange(C), (B, 1)))
+        srt = np.take_along_axis(sc, rk, axis=1)
+        ok = ok and bool(np.all(srt[:, 1:] <= srt[:, :-1]))
+        same = srt[:, 1:] == srt[:, :-1]
+        ok = ok and bool(np.all(rk[:, 1:][same] > rk[:, :-1][same]))
     print(f"case {c:3d} B={B:5d} N={N:6d} D={D:4d} k={k:5d} {style:10s} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
-print(f"{cases} cases bit-exact in {time.time() - t0:.1f} s")
+print(f"{cases} cases bit-exact (top-k) and within 1e-5 (vote) in {time.time() - t0:.1f} s")
