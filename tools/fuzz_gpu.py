@@ -16,53 +16,60 @@ import image_classification_amd as ica  # noqa: E402
 from oracle import chain  # noqa: E402
 from oracle import knn_oracle as ko  # noqa: E402
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time()
-for c in range(cases):
-    B = int(rs.choice([1, 3, 64, 255, 256, 257, 700, 1500]))
-    N = int(rs.choice([1, 7, 255, 2047, 2048, 2049, 2304, 5000, 12289, 40000, 70001]))
-    D = int(rs.choice([1, 8, 31, 32, 33, 64, 100, 128, 200, 256]))
-    k = int(min(N, rs.choice([1, 2, 63, 64, 65, 200, 256, 257, 600, 1024])))
-    style = rs.choice(["random", "clustered", "ascending", "ties"])
-    if style == "random":
-        f, x = rs.randn(B, D), rs.randn(N, D)
-    elif style == "clustered":
-        cen = rs.randn(4, D)
-        f, x = cen[rs.randint(0, 4, B)] + 0.2 * rs.randn(B, D), cen[rs.randint(0, 4, N)] + 0.2 * rs.randn(N, D)
-    elif style == "ascending":                      # every later bank row beats every earlier one
-        f = np.abs(rs.randn(B, D)) + 0.1
-        x = np.abs(rs.randn(1, D)) * np.linspace(0.1, 1.0, N)[:, None]
-    else:                                           # few distinct rows: masses of exact ties
-        f, x = rs.randn(B, D), rs.randn(5, D)[rs.randint(0, 5, N)]
-    f = ko.l2_normalize(f) if style != "ascending" else f.astype(np.float32)
-    x = ko.l2_normalize(x) if style != "ascending" else x.astype(np.float32)
-    f, x = np.ascontiguousarray(f, np.float32), np.ascontiguousarray(x, np.float32)
-    sim = chain.sim_chain_f32(f, x)
-    v_ref, i_ref = chain.topk_rows(sim, k)
-    v, i = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(x).cuda(), "fp32"), k)
-    ok = np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
-    # sorted banks: every query meets all its neighbours in one stage (class-ordered memo loader)
-    if ok and style == "clustered" and N > 4096:
-        order = np.argsort(-(x @ x[0]), kind="stable")
-        xs = np.ascontiguousarray(x[order])
-        v_ref2, i_ref2 = chain.topk_rows(chain.sim_chain_f32(f, xs), k)
-        v2, i2 = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(xs).cuda(), "fp32"), k)
-        ok = np.array_equal(v2.cpu().numpy(), v_ref2) and np.array_equal(i2.cpu().numpy(), i_ref2)
-    # vote + ranking of this case's neighbours under random labels (wave-per-row kernel for k <= 256, C <= 2048)
-    if ok:
-        C = int(rs.choice([1, 2, 10, 100, 1000, 2048, 5000]))
-        lab = rs.randint(0, C, size=N)
-        rank, scores = ica.knn_vote(v, i, torch.from_numpy(lab).cuda(), C, 0.1, return_scores=True)
-        s_ref = ko.vote_scores(ko.vote_weights(v_ref, 0.1), lab[i_ref], C)
-        sc, rk = scores.cpu().numpy(), rank.cpu().numpy()
-        ok = bool(np.all(np.isclose(sc, s_ref, rtol=1e-5, atol=1e-30)))            # inf == inf (unnormalised 'ascending' rows overflow exp)
-        ok = ok and np.array_equal(np.sort(rk, axis=1), np.tile(np.arange(C), (B, 1)))
-        srt = np.take_along_axis(sc, rk, axis=1)
-        ok = ok and bool(np.all(srt[:, 1:] <= srt[:, :-1]))
-        same = srt[:, 1:] == srt[:, :-1]
-        ok = ok and bool(np.all(rk[:, 1:][same] > rk[:, :-1][same]))
-    print(f"case {c:3d} B={B:5d} N={N:6d} D={D:4d} k={k:5d} {style:10s} {'ok' if ok else 'MISMATCH'}", flush=True)
-    if not ok:
-        sys.exit(1)
-print(f"{cases} cases bit-exact (top-k) and within 1e-5 (vote) in {time.time() - t0:.1f} s")
+def run(cases=40, seed=0, verbose=True):
+    """Returns the number of cases checked; raises AssertionError on the first mismatch."""
+    rs = np.random.RandomState(seed)
+    t0 = time.time()
+    for c in range(cases):
+        B = int(rs.choice([1, 3, 64, 255, 256, 257, 700, 1500]))
+        N = int(rs.choice([1, 7, 255, 2047, 2048, 2049, 2304, 5000, 12289, 40000, 70001]))
+        D = int(rs.choice([1, 8, 31, 32, 33, 64, 100, 128, 200, 256]))
+        k = int(min(N, rs.choice([1, 2, 63, 64, 65, 200, 256, 257, 600, 1024])))
+        style = rs.choice(["random", "clustered", "ascending", "ties"])
+        if style == "random":
+            f, x = rs.randn(B, D), rs.randn(N, D)
+        elif style == "clustered":
+            cen = rs.randn(4, D)
+            f, x = cen[rs.randint(0, 4, B)] + 0.2 * rs.randn(B, D), cen[rs.randint(0, 4, N)] + 0.2 * rs.randn(N, D)
+        elif style == "ascending":                      # every later bank row beats every earlier one
+            f = np.abs(rs.randn(B, D)) + 0.1
+            x = np.abs(rs.randn(1, D)) * np.linspace(0.1, 1.0, N)[:, None]
+        else:                                           # few distinct rows: masses of exact ties
+            f, x = rs.randn(B, D), rs.randn(5, D)[rs.randint(0, 5, N)]
+        f = ko.l2_normalize(f) if style != "ascending" else f.astype(np.float32)
+        x = ko.l2_normalize(x) if style != "ascending" else x.astype(np.float32)
+        f, x = np.ascontiguousarray(f, np.float32), np.ascontiguousarray(x, np.float32)
+        sim = chain.sim_chain_f32(f, x)
+        v_ref, i_ref = chain.topk_rows(sim, k)
+        v, i = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(x).cuda(), "fp32"), k)
+        ok = np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+        # sorted banks: every query meets all its neighbours in one stage (class-ordered memo loader)
+        if ok and style == "clustered" and N > 4096:
+            order = np.argsort(-(x @ x[0]), kind="stable")
+            xs = np.ascontiguousarray(x[order])
+            v_ref2, i_ref2 = chain.topk_rows(chain.sim_chain_f32(f, xs), k)
+            v2, i2 = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(xs).cuda(), "fp32"), k)
+            ok = np.array_equal(v2.cpu().numpy(), v_ref2) and np.array_equal(i2.cpu().numpy(), i_ref2)
+        # vote + ranking of this case's neighbours under random labels (wave-per-row kernel for k <= 256, C <= 2048)
+        if ok:
+            C = int(rs.choice([1, 2, 10, 100, 1000, 2048, 5000]))
+            lab = rs.randint(0, C, size=N)
+            rank, scores = ica.knn_vote(v, i, torch.from_numpy(lab).cuda(), C, 0.1, return_scores=True)
+            s_ref = ko.vote_scores(ko.vote_weights(v_ref, 0.1), lab[i_ref], C)
+            sc, rk = scores.cpu().numpy(), rank.cpu().numpy()
+            ok = bool(np.all(np.isclose(sc, s_ref, rtol=1e-5, atol=1e-30)))            # inf == inf (unnormalised 'ascending' rows overflow exp)
+            ok = ok and np.array_equal(np.sort(rk, axis=1), np.tile(np.arange(C), (B, 1)))
+            srt = np.take_along_axis(sc, rk, axis=1)
+            ok = ok and bool(np.all(srt[:, 1:] <= srt[:, :-1]))
+            same = srt[:, 1:] == srt[:, :-1]
+            ok = ok and bool(np.all(rk[:, 1:][same] > rk[:, :-1][same]))
+        if verbose:
+            print(f"case {c:3d} B={B:5d} N={N:6d} D={D:4d} k={k:5d} {style:10s} {'ok' if ok else 'MISMATCH'}", flush=True)
+        assert ok, f"fuzz case {c} (seed {seed}): B={B} N={N} D={D} k={k} {style}"
+    if verbose:
+        print(f"{cases} cases bit-exact (top-k) and within 1e-5 (vote) in {time.time() - t0:.1f} s")
+    return cases
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
