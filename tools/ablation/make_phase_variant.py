@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""BENCH-ONLY: build libmi_knn_phase.so, a diagnostic variant of the library whose STAMPED instantiation of the
+similarity kernel (the one mi_profile_clock switches on) records, per wave, how its K-steps split into
+
+    issue   barrier release -> every instruction of the K-step issued (operand reads, MFMAs, next K-step's DMA)
+    dma     the s_waitcnt vmcnt that follows (the wave's own LDS-DMA pieces of the next K-step landing)
+    barrier the workgroup barrier that follows (the other waves' pieces / the slowest wave)
+
+in shader cycles (s_memtime; the stamps sit where the wave's LDS queue is empty anyway).  The product sources are
+copied to a temporary directory and patched there; nothing in image-classification_amd/csrc/ carries these stamps.
+    python tools/ablation/make_phase_variant.py [suffix [extra hipcc flags]] && MI_KNN_LIB=.../libmi_knn_phase.so python tools/ablation/phase_probe.py
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.join(ROOT, "image-classification_amd")
+
+
+def rep(s, old, new):
+    assert s.count(old) == 1, (s.count(old), old)
+    return s.replace(old, new, 1)
+
+
+STAMP = ('__builtin_amdgcn_sched_barrier(0); {V} = __builtin_amdgcn_s_memtime(); '
+         'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);')
+
+with tempfile.TemporaryDirectory() as d:
+    shutil.copytree(os.path.join(PKG, "csrc"), os.path.join(d, "pkg", "csrc"))
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
+    p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
+    s = open(p).read()
+    s = rep(s, "    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {",
+            "    unsigned long long ph_issue = 0, ph_dma = 0, ph_bar = 0, ph_first = 0, ph_last = 0, ph_slow = 0, ph_hits = 0;\n"
+            "    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {\n"
+            "        unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;\n"
+            "        if constexpr (STAMP) { " + STAMP.format(V="ph0") + " }")
+    s = rep(s, "        stage_wait(pf_tag);\n        __syncthreads();\n    };",
+            "        if constexpr (STAMP) { " + STAMP.format(V="ph1") + " }\n"
+            "        stage_wait(pf_tag);\n"
+            "        if constexpr (STAMP) { " + STAMP.format(V="ph2") + " }\n"
+            "        __syncthreads();\n"
+            "        if constexpr (STAMP) { " + STAMP.format(V="ph3") + " ph_issue += ph1 - ph0; ph_dma += ph2 - ph1; ph_bar += ph3 - ph2; if (t == 0) ph_first = ph0; ph_last = ph3; }\n"
+            "    };")
+    s = rep(s, "            if (tid == 0) {\n"
+               "                const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();\n"
+               "                unsigned long long *o = p.stamps + 2ll * (bid % p.stamp_cap);\n"
+               "                o[0] = c1 - stamp_c0;\n"
+               "                o[1] = r1 - stamp_r0;\n"
+               "            }",
+            "            if (lane == 0) {      // per wave: (issue, dma), (barrier, lifetime), (prologue, epilogue), (slow entries, hits)\n"
+            "                const unsigned long long c1 = __builtin_amdgcn_s_memtime();\n"
+            "                unsigned long long *o = p.stamps + 2ll * (((long long)bid * 32 + w * 4) % p.stamp_cap);\n"
+            "                o[0] = ph_issue; o[1] = ph_dma; o[2] = ph_bar; o[3] = c1 - stamp_c0;\n"
+            "                o[4] = ph_first - stamp_c0; o[5] = c1 - ph_last; o[6] = ph_slow; o[7] = ph_hits;\n"
+            "            }")
+    s = rep(s, "                if (__any(m >= t)) {\n", "                if (__any(m >= t)) {\n                    if constexpr (STAMP) { ph_slow += 1; ph_hits += __popcll(__ballot(m >= t)); }\n")
+    open(p, "w").write(s)
+    out = os.path.join(PKG, "libmi_knn_phase%s.so" % (sys.argv[1] if len(sys.argv) > 1 else ""))
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+                          + sys.argv[2:] + ["-o", out, "mi_knn.hip"], cwd=os.path.join(d, "pkg", "csrc"))
+    print(out)
