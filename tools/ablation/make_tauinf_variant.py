@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""BENCH-ONLY: build libmi_knn_tauinf.so, a copy of the library whose filter kernel stages +inf as every row's threshold,
+so that no candidate passes whatever the operands hold (the results are meaningless).  With it the SAME instruction stream
+can be timed on random, constant and zero operands: what changes between those runs is the energy the MFMA datapath and
+the operand movement draw, i.e. the clock the chip grants (tools/ablation/toggle_probe.py).
+    python tools/ablation/make_tauinf_variant.py && MI_KNN_LIB=.../libmi_knn_tauinf.so python tools/ablation/toggle_probe.py
+"""
+import os
+import shutil
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.join(ROOT, "image-classification_amd")
+
+with tempfile.TemporaryDirectory() as d:
+    shutil.copytree(os.path.join(PKG, "csrc"), os.path.join(d, "pkg", "csrc"))
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
+    p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
+    s = open(p).read()
+    old = "((float *)(smem + SIM_LDS_BYTES))[tid] = p.tau[q0 + tid];"
+    assert s.count(old) == 1
+    s = s.replace(old, "((float *)(smem + SIM_LDS_BYTES))[tid] = INFINITY;")
+    open(p, "w").write(s)
+    out = os.path.join(PKG, "libmi_knn_tauinf.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                           "-o", out, "mi_knn.hip"], cwd=os.path.join(d, "pkg", "csrc"))
+    print(out)
