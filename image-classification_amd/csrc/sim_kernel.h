@@ -288,8 +288,13 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[2 * pp + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[u], bc[j], acc[2 * pp + u][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        // boustrophedon over the (A block, B block) grid: consecutive MFMAs share one operand, also
+                        // across groups (18 % fewer operand changes; +0.8 ... +1.8 % at C4: the clock rises, not the issue rate;
+                        // the f32 loop below gains nothing from it)
+                        const int jj = u ? 3 - j : j;
+                        acc[2 * pp + u][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[u], bc[jj], acc[2 * pp + u][jj], 0, 0, 0);
+                    }
             }
             // pin that interleave (hipcc otherwise sinks every read to just before its first use)
             MI_RD(6);
