@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""BENCH-ONLY (timing only, results wrong): copies of the library with parts of the filter epilogue's candidate
+hand-off removed, to apportion what a candidate costs in the candidate-dense early stages (tools/trace_step.sh):
+    noatomic  every hit is stored at slot 0 of its segment (no LDS slot request)
+    nostore   the slot is requested, nothing is stored
+    nohit     the hit test is kept, hits do nothing
+usage: python tools/ablation/make_epilogue_variants.py   -> image-classification_amd/libmi_knn_{noatomic,nostore,nohit}.so"""
+import os
+import shutil
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.join(ROOT, "image-classification_amd")
+OLD = "seg[atomicAdd(lcnt + rl, 1u)] = make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));"
+NEW = {
+    "noatomic": "seg[0] = make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));",
+    "nostore": "atomicAdd(lcnt + rl, 1u);",
+    "nohit": "asm volatile(\"\" :: \"v\"(v));",
+}
+for name, new in NEW.items():
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copytree(os.path.join(PKG, "csrc"), os.path.join(d, "pkg", "csrc"))
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
+        p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
+        s = open(p).read()
+        assert s.count(OLD) == 1
+        open(p, "w").write(s.replace(OLD, new))
+        out = os.path.join(PKG, f"libmi_knn_{name}.so")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                               "-o", out, "mi_knn.hip"], cwd=os.path.join(d, "pkg", "csrc"))
+        print(out)
