@@ -44,8 +44,8 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks, MI355X_M
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)      # the last warm-up step has no allocation stalls: the timed region starts on a warm clock
     ap.add_argument("--queries", type=int, default=50_000)
     ap.add_argument("--bank", type=int, default=1_280_000)
     ap.add_argument("--dim", type=int, default=2048)
