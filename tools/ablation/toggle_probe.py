@@ -14,10 +14,11 @@ from image_classification_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
-B, N, D, k = 16384, 327680, 2048, 200
+B, N, k = 16384, 327680, 200
+D = int(os.environ.get("PROBE_D", "2048"))
 xr = torch.nn.functional.normalize(torch.randn((N, D), generator=g, device=dev), dim=1)
 fr = torch.nn.functional.normalize(torch.randn((B, D), generator=g, device=dev), dim=1)
-cases = {
+cases = {f"random x random ({i})": (fr, xr) for i in range(4)} if os.environ.get("PROBE_RANDOM_ONLY") else {
     "random x random": (fr, xr),
     "random queries x zero bank": (fr, torch.zeros_like(xr)),
     "zero x zero": (torch.zeros_like(fr), torch.zeros_like(xr)),
