@@ -10,9 +10,11 @@ import csv, glob, sys
 t = sys.argv[1]
 f = glob.glob(f"gpurun_out/trace_{t}/**/r_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# the timed step = the second half of the run: find the last launch of the first kernel name of a step (pack rows)
 names = [r["Kernel_Name"] for r in rows]
-first = max(i for i, n in enumerate(names) if "pack_rows" in n and (i == 0 or "pack_rows" not in names[i - 1]))
+dense = [i for i, n in enumerate(names) if "sim_kernel<" in n and ", 0, " in n]      # bootstrap launches: the second half are the timed step's
+first = dense[len(dense) // 2]
+while first > 0 and any(t in names[first - 1] for t in ("pack", "init_state", "elementwise", "normalized")):
+    first -= 1
 out = []
 prev_end = None
 tot = {}
