@@ -181,6 +181,11 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
+    // The first operand stage goes out before anything else is set up: the prefetch pointers, the operand read
+    // offsets and the staging of the thresholds below run while it is in flight.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_pair(i, 0, 0);
+
 #if MI_L2_PREFETCH
     // ---- L2 prefetch.  The 32 workgroups of an XCD patch stream the same 8 + 4 operand tiles, so 19 % of the
     // DMA requests -- the first touch of every line in this XCD -- miss the L2 and take the Infinity-Cache
@@ -356,9 +361,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #undef MI_RD
 #undef MI_MM
 
-#pragma unroll
-    for (int i = 0; i < 4; ++i) stage_pair(i, 0, 0);
-    stage_wait(std::false_type{});
+    stage_wait(std::false_type{});                   // the first operand stage (issued at the top) and the thresholds
     __syncthreads();
 #if MI_L2_PREFETCH
     for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{});
