@@ -10,5 +10,5 @@ tail -3 $R/gpurun_out/t_$T.log
 timeout -k 10 400 python bench.py > $R/gpurun_out/b_$T.json 2> $R/gpurun_out/b_$T.err || { tail -20 $R/gpurun_out/b_$T.err; exit 1; }
 cat $R/gpurun_out/b_$T.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T -o r -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$T.json 2> $R/gpurun_out/prof_$T.err || { tail -20 $R/gpurun_out/prof_$T.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T -o r -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$T.json 2> $R/gpurun_out/prof_$T.err || { tail -20 $R/gpurun_out/prof_$T.err; exit 1; }
 find $R/gpurun_out/prof_$T -name '*kernel_stats.csv' | head -1

@@ -4,6 +4,7 @@ set -o pipefail
 T=$1; S=$2
 R=$GRAFT_REPO_ROOT
 LIB=$R/image-classification_amd/libmi_knn$S.so
+mkdir -p $R/gpurun_out/pmc_$T
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" \
