@@ -16,7 +16,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 B, N, D, k = 16384, int(os.environ.get("PROBE_N", "327680")), 2048, 200
 x = torch.nn.functional.normalize(torch.randn((N, D), generator=g, device=dev), dim=1)
 f = torch.nn.functional.normalize(torch.randn((B, D), generator=g, device=dev), dim=1)
-bank = ica.BankIndex.from_rows(x, "bf16")
+DT = os.environ.get("PROBE_DTYPE", "bf16")
+bank = ica.BankIndex.from_rows(x, DT)
 for _ in range(3):
     ica.knn_topk(f, bank, k)
 torch.cuda.synchronize()
@@ -30,7 +31,7 @@ _lib.check(_lib.lib().mi_profile_clock(None, 0), "clock")
 r = st.cpu().double().view(-1, 8, 8)              # [workgroup, wave, (issue, dma, barrier, lifetime, prologue, epilogue, slow, hits)]
 ok = r[:, :, 3].min(dim=1).values > 0
 r = r[ok]
-ksteps = D * 2 // 128
+ksteps = D * (2 if DT == "bf16" else 4) // 128
 print(f"{r.shape[0]} workgroups, {ksteps} K-steps per tile; median cycles per K-step and wave")
 for w in range(8):
     i, d, b, life, pre, post = (float(r[:, w, j].median()) for j in range(6))
