@@ -107,15 +107,6 @@ __device__ __forceinline__ float row16_sum(float v)
 #ifndef MI_PF_DIST
 #define MI_PF_DIST 2
 #endif
-#ifndef MI_PINGPONG_F32
-#define MI_PINGPONG_F32 1
-#endif
-#ifndef MI_PINGPONG_MIN_KSTEPS
-#define MI_PINGPONG_MIN_KSTEPS 8
-#endif
-#ifndef MI_PINGPONG_BF16
-#define MI_PINGPONG_BF16 0
-#endif
 #ifndef MI_PF_POS
 #define MI_PF_POS 4
 #endif
@@ -265,47 +256,28 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     // (the reads of group g+1 are issued before the MFMAs of group g, two register sets) and the
     // next K-step's DMA is spread over the first four groups (one A + one B piece each) instead of
     // being issued as a burst: a burst keeps BOTH waves of a SIMD out of the matrix pipe at once.
-    auto kstep = [&](int t, auto dma_tag, auto pf_tag, auto set_tag) {
+    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {
         constexpr bool DMA = decltype(dma_tag)::value;
         constexpr bool PF = decltype(pf_tag)::value;
-        // SET 0: both waves of a SIMD run the K-step side by side, DMA issue spread over the MFMA groups.
-        // SET 1 / 2 (ping-pong): the waves of the first half (1) run their MFMAs while those of the second half (2)
-        // issue their DMA and wait at a mid-step barrier, then the roles swap: a wave that has the matrix pipe to
-        // itself issues at the instruction's rate, two contending waves do not.
-        constexpr int SET = decltype(set_tag)::value;
-        auto memory_phase = [&]() {
-            if constexpr (DMA) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) stage_pair(i, t + 1, (t + 1) & 1);
-            }
-            if constexpr (PF) prefetch(t + MI_PF_DIST);
-        };
-        auto mid_barrier = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-        };
         const char *lds = smem + (t & 1) * STAGE_BYTES;
         const int nbuf = (t + 1) & 1;
         if constexpr (DT == DT_BF16) {
             const int coff0 = (lq ^ sw) * 16, coff1 = coff0 ^ 64;
             const char *la = lds + a_row_off, *lb = lds + b_row_off;
             bf16x8 b0[4], b1[4], a0[2], a1[2];
-            if constexpr (SET == 2) memory_phase();
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = *(const bf16x8 *)(lb + j * 2048 + coff0);
             a0[0] = *(const bf16x8 *)(la + coff0);
             a0[1] = *(const bf16x8 *)(la + 2048 + coff0);
-            if constexpr (SET == 2) mid_barrier();
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {          // pr = s * 4 + pair
                 const int s = pr >> 2, pp = pr & 3;
                 bf16x8 *ac = (pr & 1) ? a1 : a0, *an = (pr & 1) ? a0 : a1;
                 bf16x8 *bc = s ? b1 : b0;
-                if constexpr (DMA && SET == 0) {
+                if constexpr (DMA) {
                     if (pr < 4) stage_pair(pr, t + 1, nbuf);
                 }
-                if constexpr (PF && SET == 0) {
+                if constexpr (PF) {
                     if (pr == MI_PF_POS) prefetch(t + MI_PF_DIST);
                 }
                 if (pr < 7) {
@@ -339,12 +311,10 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             MI_RD(2); MI_MM(8);
             MI_RD(2); MI_MM(8);
             MI_MM(8);
-            if constexpr (SET == 1) { mid_barrier(); memory_phase(); }
         } else {
             // f32: 8 sub-steps of 4 k each; v_mfma_f32_16x16x4_f32 chains k ascending (bit-exact order)
             const char *la = lds + a_row_off, *lb = lds + b_row_off;
             float a0[8], a1[8], b0[4], b1[4];
-            if constexpr (SET == 2) memory_phase();
             {
                 const int co = (sw * 16) + lq * 4;          // kk = 0
 #pragma unroll
@@ -352,15 +322,14 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b0[j] = *(const float *)(lb + j * 2048 + co);
             }
-            if constexpr (SET == 2) mid_barrier();
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 float *ac = (kk & 1) ? a1 : a0, *an = (kk & 1) ? a0 : a1;
                 float *bc = (kk & 1) ? b1 : b0, *bn = (kk & 1) ? b0 : b1;
-                if constexpr (DMA && SET == 0) {
+                if constexpr (DMA) {
                     if (kk < 4) stage_pair(kk, t + 1, nbuf);
                 }
-                if constexpr (PF && SET == 0) {
+                if constexpr (PF) {
                     if (kk == 4) prefetch(t + MI_PF_DIST);
                 }
                 if (kk < 7) {
@@ -376,16 +345,17 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i], bc[j], acc[i][j], 0, 0, 0);
             }
-            MI_RD(12);
-            MI_RD(12); MI_MM(32);
-            MI_RD(12); MI_MM(32);
-            MI_RD(12); MI_MM(32);
-            MI_RD(12); MI_MM(32);
-            MI_RD(12); MI_MM(32);
-            MI_RD(12); MI_MM(32);
-            MI_RD(12); MI_MM(32);
+            // hipcc pairs the 12 dword reads of a sub-step into 6 ds_read2st64_b32; one of them after every 5 MFMAs stays
+            // inside the 32-cycle MFMA's issue shadow (issued as a burst they hold the wave's issue for ~100 cycles per
+            // two sub-steps: C3 f32 125 -> 132 TFLOP/s)
+            MI_RD(6);
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                MI_RD(1); MI_MM(5); MI_RD(1); MI_MM(5); MI_RD(1); MI_MM(5);
+                MI_RD(1); MI_MM(5); MI_RD(1); MI_MM(5); MI_RD(1); MI_MM(5);
+                MI_MM(2);
+            }
             MI_MM(32);
-            if constexpr (SET == 1) { mid_barrier(); memory_phase(); }
         }
         stage_wait(pf_tag);
         __syncthreads();
@@ -396,32 +366,14 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     stage_wait(std::false_type{});                   // the first operand stage (issued at the top) and the thresholds
     __syncthreads();
 #if MI_L2_PREFETCH
-#define MI_KLOOP(set)                                                                                       \
-    do {                                                                                                    \
-        for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{}, set);           \
-        if (p.ksteps > 1) kstep(p.ksteps - 2, std::true_type{}, std::false_type{}, set);                    \
-        kstep(p.ksteps - 1, std::false_type{}, std::false_type{}, set);                                     \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the last touches have landed before LDS is reused */ \
-    } while (0)
+    for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{});
+    if (p.ksteps > 1) kstep(p.ksteps - 2, std::true_type{}, std::false_type{});
+    kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the last touches have landed before LDS is reused
 #else
-#define MI_KLOOP(set)                                                                                       \
-    do {                                                                                                    \
-        for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{}, std::false_type{}, set);          \
-        kstep(p.ksteps - 1, std::false_type{}, std::false_type{}, set);                                     \
-    } while (0)
+    for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{}, std::false_type{});
+    kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
 #endif
-    // Ping-pong pays where one wave alone keeps the matrix pipe full and the K loop is long: the f32 filter (a 32-cycle
-    // MFMA; +2.5 % at D = 2048, +0.9 % at D = 256, -1 % at D = 128: off below 8 K-steps).  bf16 needs both waves of a SIMD side by side (ping-pong: -20 %).
-    constexpr bool PINGPONG = MODE == MODE_FILTER && (DT == DT_F32 ? MI_PINGPONG_F32 : MI_PINGPONG_BF16);
-    if constexpr (PINGPONG) {
-        auto kloop = [&](auto set) { MI_KLOOP(set); };
-        if (p.ksteps < MI_PINGPONG_MIN_KSTEPS) kloop(std::integral_constant<int, 0>{});
-        else if (w < 4) kloop(std::integral_constant<int, 1>{});
-        else kloop(std::integral_constant<int, 2>{});
-    } else {
-        MI_KLOOP((std::integral_constant<int, 0>{}));
-    }
-#undef MI_KLOOP
 
     // ---- epilogue.  C/D map of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int row_base = q0 + wm * 128 + lq * 4;          // + i*16 + reg

@@ -33,9 +33,9 @@ with tempfile.TemporaryDirectory() as d:
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
     p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
     s = open(p).read()
-    s = rep(s, "    auto kstep = [&](int t, auto dma_tag, auto pf_tag, auto set_tag) {",
+    s = rep(s, "    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {",
             "    unsigned long long ph_issue = 0, ph_dma = 0, ph_bar = 0, ph_first = 0, ph_last = 0, ph_slow = 0, ph_hits = 0;\n"
-            "    auto kstep = [&](int t, auto dma_tag, auto pf_tag, auto set_tag) {\n"
+            "    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {\n"
             "        unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;\n"
             "        if constexpr (STAMP) { " + STAMP.format(V="ph0") + " }")
     s = rep(s, "        stage_wait(pf_tag);\n        __syncthreads();\n    };",

@@ -22,16 +22,16 @@ with tempfile.TemporaryDirectory() as d:
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
     p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
     s = open(p).read()
-    s = rep(s, "    auto kstep = [&](int t, auto dma_tag, auto pf_tag, auto set_tag) {",
+    s = rep(s, "    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {",
             "    unsigned long long sub[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};\n"
-            "    auto kstep = [&](int t, auto dma_tag, auto pf_tag, auto set_tag) {\n"
+            "    auto kstep = [&](int t, auto dma_tag, auto pf_tag) {\n"
             "        unsigned long long ts[10];")
     s = rep(s, "            for (int kk = 0; kk < 8; ++kk) {\n                float *ac = (kk & 1) ? a1 : a0, *an = (kk & 1) ? a0 : a1;\n",
             "            for (int kk = 0; kk < 8; ++kk) {\n"
             "                if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[kk] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }\n"
             "                float *ac = (kk & 1) ? a1 : a0, *an = (kk & 1) ? a0 : a1;\n")
-    s = rep(s, "            MI_RD(12); MI_MM(32);\n            MI_MM(32);\n",
-            "            MI_RD(12); MI_MM(32);\n            MI_MM(32);\n"
+    s = rep(s, "                MI_MM(2);\n            }\n            MI_MM(32);\n",
+            "                MI_MM(2);\n            }\n            MI_MM(32);\n"
             "            if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[8] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }\n")
     s = rep(s, "        stage_wait(pf_tag);\n        __syncthreads();\n    };",
             "        stage_wait(pf_tag);\n        __syncthreads();\n"
