@@ -903,6 +903,9 @@ int mi_bank_scatter(void *bank, int64_t K, int64_t row_bytes, const int64_t *ind
 
 // ------------------------------------------------------------------ MoCo queue logits
 namespace {
+#ifndef MI_MOCO_BWD_WGS
+#define MI_MOCO_BWD_WGS 512
+#endif
 struct MocoPlan { int b_pad, ntiles, lse_ld; size_t off_part, off_rowloss, fwd_total; int nslices, rows_per_slice; size_t bwd_total, total; };
 MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
 {
@@ -913,10 +916,10 @@ MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
     m.off_part = 0;
     m.off_rowloss = (size_t)round_up((int64_t)m.ntiles * m.lse_ld * 8, 256);      // the arrival counter (own line) + per-block loss sums
     m.fwd_total = m.off_rowloss + 256 + (size_t)round_up((int64_t)ceil_div(b, 16) * 4, 256);
-    // backward: ~256 workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
+    // backward: ~MI_MOCO_BWD_WGS workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
     const int64_t qtiles = ceil_div(b, mi::MB_ROWS);
     const int64_t ktiles = ceil_div(K, mi::MB_ROWS);
-    int64_t ns = ceil_div(256, qtiles);
+    int64_t ns = ceil_div(MI_MOCO_BWD_WGS, qtiles);
     if (ns > ktiles) ns = ktiles;
     if (ns < 1) ns = 1;
     m.rows_per_slice = (int)(ceil_div(ktiles, ns) * mi::MB_ROWS);
@@ -981,6 +984,8 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
     if (!dq && !dkey) return fail(MI_ERR_ARG, "mi_moco_bwd: dq and dkey are both null");
     if (b < 1 || K < 1 || D < 1 || b > (1 << 24) || K > INT32_MAX - 2 * mi::TILE) return fail(MI_ERR_ARG, "mi_moco_bwd: bad shape");
     if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_moco_bwd: temperature must be positive");
+    if (D % 4) return fail(MI_ERR_UNSUPPORTED, "mi_moco_bwd: D=%lld must be a multiple of 4 (of 64 for dq)", (long long)D);
+    if (((uintptr_t)q | (uintptr_t)key | (uintptr_t)dq | (uintptr_t)dkey) & 15) return fail(MI_ERR_ARG, "mi_moco_bwd: q, key, dq, dkey must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const float inv_t = 1.0f / temperature;
     int nslices = 0;
@@ -1021,7 +1026,7 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
 #undef MI_LAUNCH_BWD
         HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(mi::moco_bwd_reduce_kernel, dim3((unsigned)ceil_div(b * D, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(mi::moco_bwd_reduce_kernel, dim3((unsigned)ceil_div(b * D / 4, 16)), dim3(256), 0, s,
                        (const float *)workspace, nslices, (int)b, (int)D, q, key, lse, lpos, grad_loss, inv_t, dq, dkey);
     HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -1030,13 +1035,16 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
 // ------------------------------------------------------------------ CoMatch soft-kNN smoothing
 extern "C++" {
 namespace {
+#ifndef MI_SOFT_WGS
+#define MI_SOFT_WGS 256
+#endif
 struct SoftPlan { int V, nslices, rows_per_slice; size_t total; };
 SoftPlan soft_plan(int64_t b, int64_t K, int64_t C)
 {
     SoftPlan sp{};
     sp.V = (int)round_up(C + 1, 64);                       // + the row-sum column
     const int64_t qtiles = ceil_div(b, mi::MB_ROWS), ktiles = ceil_div(K, mi::MB_ROWS);
-    int64_t ns = ceil_div(256, qtiles);
+    int64_t ns = ceil_div(MI_SOFT_WGS, qtiles);
     if (ns > ktiles) ns = ktiles;
     if (ns < 1) ns = 1;
     sp.rows_per_slice = (int)(ceil_div(ktiles, ns) * mi::MB_ROWS);

@@ -47,7 +47,8 @@ struct AttendParams {
 
 inline size_t attend_lds_bytes(int D, int V, bool separate_vals)
 {
-    return (size_t)(2 * MB_ROWS * (D + 4) + (separate_vals ? MB_ROWS * (V + 4) : 0) + 4 * 16 * MB_PLD) * 4;
+    // bank tile + (soft-kNN) value tile + one weight patch per wave; the query tile lives in registers
+    return (size_t)(MB_ROWS * (D + 4) + (separate_vals ? MB_ROWS * (V + 4) : 0) + 4 * 16 * MB_PLD) * 4;
 }
 
 template <int D64, int V64, bool SOFT>      // D / 64, V / 64 (values); !SOFT: the values ARE the bank rows (V64 == D64)
@@ -59,8 +60,7 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
     constexpr int LOADS = MB_ROWS * D / 4 / MB_THREADS;      // float4 per thread and feature tile = D / 16
     constexpr int VLOADS = SOFT ? MB_ROWS * V / MB_THREADS : 1;   // floats per thread and value tile = V / 4
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *sq = lds;                                  // [64][LD] query tile
-    float *sx = sq + MB_ROWS * LD;                    // [64][LD] bank tile
+    float *sx = lds;                                  // [64][LD] bank tile
     float *sv = SOFT ? sx + MB_ROWS * LD : sx;        // [64][LV] value tile (soft-kNN) / the bank tile itself
     float *sp = sv + (SOFT ? MB_ROWS * LV : MB_ROWS * LD);   // [4][16][MB_PLD] weights, one patch per wave
     constexpr int SLD = SOFT ? LV : LD;
@@ -111,14 +111,16 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
         }
     };
 
-    // query tile -> LDS (rows past b are zero; MoCo gives them lse = +inf below: their weight is exactly 0;
-    // soft-kNN rows past b are simply not written out)
+    // query operand -> registers, once: lane (lr, lq) of wave w holds row 16w + lr, columns 16g + 4lq .. + 3 of every
+    // 16-column group g (the A operand of the first GEMM; D / 4 registers).  Rows past b are zero (MoCo gives them
+    // lse = +inf below: their weight is exactly 0; soft-kNN rows past b are simply not written out).  Keeping it out of
+    // LDS (33 KiB at D = 128) lets three workgroups share a CU instead of one.
+    float4 aq[D / 16];
+    {
+        const int row = q0 + 16 * w + lr;
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-        const int e = tid + i * MB_THREADS, r = e / (D / 4), c = e % (D / 4);
-        const int row = q0 + r;
-        *(float4 *)(sq + r * LD + c * 4) =
-            row < p.b ? *(const float4 *)(p.q + (long long)row * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < D / 16; ++g)
+            aq[g] = row < p.b ? *(const float4 *)(p.q + (long long)row * D + 16 * g + 4 * lq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float lse_r[4];
 #pragma unroll
@@ -144,15 +146,20 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
         for (int nb = 0; nb < 4; ++nb) s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < D / 16; ++g) {
-            const float4 a = *(const float4 *)(sq + (16 * w + lr) * LD + 16 * g + 4 * lq);
+            const float4 a = aq[g];
+            float4 x[4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const float4 x = *(const float4 *)(sx + (16 * nb + lr) * LD + 16 * g + 4 * lq);
-                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, s[nb], 0, 0, 0);
-                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, s[nb], 0, 0, 0);
-                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, s[nb], 0, 0, 0);
-                s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, s[nb], 0, 0, 0);
-            }
+            for (int nb = 0; nb < 4; ++nb) x[nb] = *(const float4 *)(sx + (16 * nb + lr) * LD + 16 * g + 4 * lq);
+            // the four accumulators take turns: a v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result is
+            // only ready after 40, and this kernel runs one wave per SIMD (each accumulator still sees k ascending)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[nb].x, s[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[nb].y, s[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[nb].z, s[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[nb].w, s[nb], 0, 0, 0);
         }
         // weights = exp(S / T - lse), columns past the slice end are 0; C layout -> LDS patch [row][n]
 #pragma unroll
@@ -198,22 +205,50 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
 // dq[i][d]   = g * inv_t / b * ( sum_s part[s][i][d] + (p_pos_i - 1) * key[i][d] )      p_pos_i = exp(lpos_i * inv_t - lse_i)
 // dkey[i][d] = g * inv_t / b * (p_pos_i - 1) * q[i][d]            (the positive logit q_i . key_i is the only term with key)
 // Either output may be null (dq == nullptr: `part` is not read).
+// 256 threads = 16 float4 columns x 16 slice groups: group g adds slices g, g + 16, ... (all its loads in flight
+// together), the 16 group sums meet in LDS and are added in group order -- a fixed order, so the result does not depend
+// on timing.  (One thread per element walking all slices read the partials at 0.5 TB/s.)
+constexpr int RED_GROUPS = 16;
 __global__ __launch_bounds__(256) void moco_bwd_reduce_kernel(const float *part, int nslices, int b, int D,
                                                               const float *q, const float *key, const float *lse,
                                                               const float *lpos, const float *grad_loss, float inv_t,
                                                               float *dq, float *dkey)
 {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)b * D) return;
+    __shared__ float4 sm[RED_GROUPS][16];
+    const long long n4 = (long long)b * D / 4;                 // D % 64 == 0
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long long e4 = (long long)blockIdx.x * 16 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dq && e4 < n4) {
+        const float4 *p4 = (const float4 *)part + e4;
+#pragma unroll 8
+        for (int sl = grp; sl < nslices; sl += RED_GROUPS) {
+            const float4 v = p4[(long long)sl * n4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sm[grp][col] = s;
+    __syncthreads();
+    if (grp != 0 || e4 >= n4) return;
+#pragma unroll
+    for (int g = 1; g < RED_GROUPS; ++g) {
+        const float4 v = sm[g][col];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long long e = e4 * 4;
     const int row = (int)(e / D);
     const float ppos = __expf(lpos[row] * inv_t - lse[row]);
     const float scale = grad_loss[0] * inv_t / (float)b;
     if (dq) {
-        float s = 0.f;
-        for (int sl = 0; sl < nslices; ++sl) s += part[(long long)sl * b * D + e];
-        dq[e] = scale * (s + (ppos - 1.f) * key[e]);
+        const float4 kv = *(const float4 *)(key + e);
+        *(float4 *)(dq + e) = make_float4(scale * (s.x + (ppos - 1.f) * kv.x), scale * (s.y + (ppos - 1.f) * kv.y),
+                                          scale * (s.z + (ppos - 1.f) * kv.z), scale * (s.w + (ppos - 1.f) * kv.w));
     }
-    if (dkey) dkey[e] = scale * (ppos - 1.f) * q[e];
+    if (dkey) {
+        const float4 qv = *(const float4 *)(q + e);
+        *(float4 *)(dkey + e) = make_float4(scale * (ppos - 1.f) * qv.x, scale * (ppos - 1.f) * qv.y,
+                                            scale * (ppos - 1.f) * qv.z, scale * (ppos - 1.f) * qv.w);
+    }
 }
 
 // probs_out[i][c] = alpha * probs_in[i][c] + (1 - alpha) * (sum_s part[s][i][c]) / (sum_s part[s][i][C])

@@ -183,7 +183,7 @@ int mi_moco_fwd(const float *q, const float *key, const float *queue, int64_t b,
  * The probabilities are recomputed tile by tile from q, queue and lse (never stored).
  * grad_loss: device pointer to the upstream scalar gradient.  dq needs D % 64 == 0, D <= 256 and the workspace
  * (mi_moco_workspace_bytes covers forward and backward); with dq == NULL queue/workspace may be NULL and any D
- * the forward accepts is fine.
+ * the forward accepts is fine.  q, key, dq, dkey: 16-byte aligned.
  * The reference pushes into the queue BEFORE backward (moco.py:159-172) and therefore clones the
  * whole queue every step (moco.py:153).  Here the caller may pass the live, already pushed-into
  * queue plus the rows the push overwrote: queue rows [patch_lo, patch_lo + patch_n) are read from
@@ -198,8 +198,7 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
  *   A = exp(feature @ bank_feature^T / T) ; A = A / A.sum(1) ; probs_out = alpha*probs_in + (1-alpha) * A @ bank_prob
  * (plain exp without max subtraction, as the reference) without writing the [b, K] matrix A.
  * feature [b, D], bank_feature [K, D], bank_prob [K, C], probs_in/probs_out [b, C], all float32 row-major.
- * D % 64 == 0, 1 <= C <= 255, and the tiles must fit the 160 KiB LDS: D <= 128 with any C, D = 192 with
- * C <= 127 (MI_ERR_UNSUPPORTED otherwise; the reference's feature_dim is 64). */
+ * D % 64 == 0, 64 <= D <= 256, 1 <= C <= 255 (MI_ERR_UNSUPPORTED otherwise; the reference's feature_dim is 64). */
 size_t mi_soft_knn_workspace_bytes(int64_t b, int64_t K, int64_t D, int64_t C);
 int mi_soft_knn(const float *feature, const float *bank_feature, const float *bank_prob, const float *probs_in,
                 int64_t b, int64_t K, int64_t D, int64_t C, float temperature, float alpha, float *probs_out,
