@@ -465,7 +465,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (col_base + j * 16 < col_end) s += expf(acc[i][j][r] * p.inv_t - m);
+                    if (col_base + j * 16 < col_end) s += __expf(acc[i][j][r] * p.inv_t - m);     // v_exp_f32: ~1e-7 relative, as in the backward
                 s = row16_sum(s);
                 if (lr == 0) lpart[(wm * 128 + lq * 4 + i * 16 + r) * 4 + wn] = make_float2(m, s);
             }
