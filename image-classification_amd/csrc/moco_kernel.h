@@ -140,27 +140,43 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
         __syncthreads();
         if (n0 + MB_ROWS < n_end) prefetch(n0 + MB_ROWS);     // in flight during both GEMMs
 
-        // S[16 x 64] = q rows (16w ..) . tile rows^T
+        // S[16 x 64] = q rows (16w ..) . tile rows^T.  The bank operand of column group g + 1 is read while the MFMAs of
+        // group g run (two register sets, one read per four MFMAs, pinned: hipcc otherwise sinks every read to just
+        // before its first use and the wave waits out the LDS latency 8 times per tile).  The four accumulators take
+        // turns: a v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result is ready after 40.
         f32x4 s[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 x0[4], x1[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) x0[nb] = *(const float4 *)(sx + (16 * nb + lr) * LD + 4 * lq);
 #pragma unroll
         for (int g = 0; g < D / 16; ++g) {
             const float4 a = aq[g];
-            float4 x[4];
+            float4 *xc = (g & 1) ? x1 : x0, *xn = (g & 1) ? x0 : x1;
+            if (g + 1 < D / 16) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) x[nb] = *(const float4 *)(sx + (16 * nb + lr) * LD + 16 * g + 4 * lq);
-            // the four accumulators take turns: a v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result is
-            // only ready after 40, and this kernel runs one wave per SIMD (each accumulator still sees k ascending)
+                for (int nb = 0; nb < 4; ++nb) xn[nb] = *(const float4 *)(sx + (16 * nb + lr) * LD + 16 * (g + 1) + 4 * lq);
+            }
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[nb].x, s[nb], 0, 0, 0);
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, xc[nb].x, s[nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[nb].y, s[nb], 0, 0, 0);
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, xc[nb].y, s[nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[nb].z, s[nb], 0, 0, 0);
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, xc[nb].z, s[nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[nb].w, s[nb], 0, 0, 0);
+            for (int nb = 0; nb < 4; ++nb) s[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, xc[nb].w, s[nb], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int g = 0; g + 1 < D / 16; ++g) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         // weights = exp(S / T - lse), columns past the slice end are 0; C layout -> LDS patch [row][n]
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -173,20 +189,48 @@ __global__ __launch_bounds__(MB_THREADS) void attend_kernel(const AttendParams p
                 spw[(4 * lq + r) * MB_PLD + 16 * nb + lr] = ok ? wgt : 0.f;
             }
         }
-        __syncthreads();
-        // out[16 x V] += W[16 x 64] . values[64 x V]; block c*4+j holds columns 64c + 4*(lane&15) + j
+        // the patch is wave private and a wave's LDS operations complete in order: no workgroup barrier between its
+        // stores above and its loads below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // out[16 x V] += W[16 x 64] . values[64 x V]; block c*4+j holds columns 64c + 4*(lane&15) + j.  Operands of
+        // step kk + 1 are read under the MFMAs of step kk (pinned as above).
+        float wa[2];
+        float4 v0[V64], v1[V64];
+        wa[0] = spw[lr * MB_PLD + lq];
+#pragma unroll
+        for (int c = 0; c < V64; ++c) v0[c] = *(const float4 *)(sv + lq * SLD + 64 * c + 4 * lr);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const float a = spw[lr * MB_PLD + 4 * kk + lq];
+            const float a = wa[kk & 1];
+            float4 *vc = (kk & 1) ? v1 : v0, *vn = (kk & 1) ? v0 : v1;
+            if (kk < 15) {
+                wa[(kk + 1) & 1] = spw[lr * MB_PLD + 4 * (kk + 1) + lq];
+#pragma unroll
+                for (int c = 0; c < V64; ++c) vn[c] = *(const float4 *)(sv + (4 * (kk + 1) + lq) * SLD + 64 * c + 4 * lr);
+            }
 #pragma unroll
             for (int c = 0; c < V64; ++c) {
-                const float4 x = *(const float4 *)(sv + (4 * kk + lq) * SLD + 64 * c + 4 * lr);
-                acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.x, acc[c * 4 + 0], 0, 0, 0);
-                acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.y, acc[c * 4 + 1], 0, 0, 0);
-                acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.z, acc[c * 4 + 2], 0, 0, 0);
-                acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x.w, acc[c * 4 + 3], 0, 0, 0);
+                acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vc[c].x, acc[c * 4 + 0], 0, 0, 0);
+                acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vc[c].y, acc[c * 4 + 1], 0, 0, 0);
+                acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vc[c].z, acc[c * 4 + 2], 0, 0, 0);
+                acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vc[c].w, acc[c * 4 + 3], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + V64, 0);
+#pragma unroll
+        for (int kk = 0; kk < 15; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+            for (int c = 0; c < V64; ++c) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (c + 1 < V64) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * V64, 0);
     }
     // partial of this slice
     float *part = p.part + (long long)blockIdx.y * p.b * V;
