@@ -149,35 +149,6 @@ class ShardedKnn:
         self.n_total = sum(sizes)
 
     # -- one exchange step ------------------------------------------------------------------
-    # -- one exchange step ------------------------------------------------------------------
-    # -- collectives: ONE call site each, whatever the backend --------------------------------
-    def _on_device(self) -> bool:
-        """RCCL (backend "nccl") moves device tensors itself; any other backend (gloo in the CPU tests and in the
-        two-ranks-on-one-GPU test) gets the SAME collective call with the SAME split sizes on host copies."""
-        return dist.get_backend(self.group) == "nccl"
-
-    def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, out_splits, in_splits):
-        """recv <- all_to_all_single(send); returns the pending work (None once complete)."""
-        if self._on_device():
-            return dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits,
-                                          group=self.group, async_op=True)
-        hrecv = torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_to_all_single(hrecv, send.cpu().contiguous(), output_split_sizes=out_splits,
-                               input_split_sizes=in_splits, group=self.group)
-        recv.copy_(hrecv)
-        return None
-
-    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor, async_op: bool = False):
-        """out [G * n, ...] <- all_gather_into_tensor(mine [n, ...]); returns the pending work (None once complete)."""
-        if self._on_device():
-            w = dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group, async_op=async_op)
-            return w if async_op else None
-        hout = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(hout, mine.cpu().contiguous(), group=self.group)
-        out.copy_(hout)
-        return None
-
-    # -- one exchange step ------------------------------------------------------------------
     def _exchange(self, val: torch.Tensor, idx: torch.Tensor):
         """all-gather [B, k] candidates -> [G, B, k]; returns (gathered_val, gathered_idx, works)."""
         if self.solo:
