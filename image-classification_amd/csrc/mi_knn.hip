@@ -71,7 +71,6 @@ struct ProfScope {
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
-inline int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
 
 // --------------------------------------------------------------------------- small kernels
 // pack: float32 source -> compute dtype, K-contiguous rows, zero padded to ld_dst.
