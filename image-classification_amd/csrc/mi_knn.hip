@@ -1114,7 +1114,7 @@ int mi_soft_knn(const float *feature, const float *bank_feature, const float *ba
     default: e = launch_soft_v<4>(v64, ap, grid, lds, s); break;
     }
     HIP_CHECK(e);
-    hipLaunchKernelGGL(mi::soft_knn_reduce_kernel, dim3((unsigned)ceil_div(b * C, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(mi::soft_knn_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s,
                        (const float *)workspace, sp.nslices, (int)b, sp.V, (int)C, probs_in, alpha, probs_out);
     HIP_CHECK(hipGetLastError());
     return MI_OK;

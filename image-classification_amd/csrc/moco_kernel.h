@@ -296,19 +296,42 @@ __global__ __launch_bounds__(256) void moco_bwd_reduce_kernel(const float *part,
 }
 
 // probs_out[i][c] = alpha * probs_in[i][c] + (1 - alpha) * (sum_s part[s][i][c]) / (sum_s part[s][i][C])
+// One workgroup per row: V / 4 float4 columns x (1024 / V) slice groups; group g adds slices g, g + groups, ... with all its
+// loads in flight, the group sums meet in LDS and are added in group order (fixed order: deterministic).
 __global__ __launch_bounds__(256) void soft_knn_reduce_kernel(const float *part, int nslices, int b, int V, int C,
                                                               const float *probs_in, float alpha, float *probs_out)
 {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)b * C) return;
-    const int row = (int)(e / C), c = (int)(e - (long long)row * C);
-    float num = 0.f, den = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) {
-        const float *pr = part + ((long long)sl * b + row) * V;
-        num += pr[c];
-        den += pr[C];
+    __shared__ float4 sm[256];
+    __shared__ float rowsum[256];
+    const int row = blockIdx.x;
+    const int cols4 = V >> 2;                                  // 16, 32, 48 or 64
+    const int groups = 256 / cols4;                            // 16, 8, 5 or 4 (threads past groups * cols4 idle)
+    const int col = threadIdx.x % cols4, grp = threadIdx.x / cols4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grp < groups) {
+        const float4 *p4 = (const float4 *)(part + (long long)row * V) + col;
+        const long long stride4 = (long long)b * V / 4;
+#pragma unroll 4
+        for (int sl = grp; sl < nslices; sl += groups) {
+            const float4 v = p4[(long long)sl * stride4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    probs_out[e] = alpha * probs_in[e] + (1.f - alpha) * (num / den);
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0) {
+        for (int g = 1; g < groups; ++g) {
+            const float4 v = sm[g * cols4 + col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        rowsum[4 * col + 0] = s.x; rowsum[4 * col + 1] = s.y; rowsum[4 * col + 2] = s.z; rowsum[4 * col + 3] = s.w;
+    }
+    __syncthreads();
+    const float den = rowsum[C];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const long long e = (long long)row * C + c;
+        probs_out[e] = alpha * probs_in[e] + (1.f - alpha) * (rowsum[c] / den);
+    }
 }
 
 // Ring-buffer enqueue that first saves the rows it overwrites (16-byte units).
