@@ -362,6 +362,16 @@ def test_rccl_branches_on_one_rank_group(ica):
         assert torch.equal(knn.local_ranking, ref) and torch.equal(knn.local_rows.cpu(), torch.arange(700))
         v, i = knn.topk(dev(f), k)
         assert torch.equal(v, v_ref) and torch.equal(i, i_ref)
+        # the message sizes of a real 8-rank job (bench.py --gpus 8: one 50 000-row chunk against a 160 000 x 2048 shard,
+        # 80 MB of packed candidates through all_to_all_single, 50 000 top-1 labels through all_gather_into_tensor)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        xb = torch.nn.functional.normalize(torch.randn((160_000, 2048), generator=g, device="cuda"), dim=1)
+        fb = torch.nn.functional.normalize(torch.randn((50_000, 2048), generator=g, device="cuda"), dim=1)
+        labb = torch.randint(0, 1000, (160_000,), generator=g, device="cuda")
+        big = ica.sharded.ShardedKnn(xb, 0, compute_dtype="bf16", query_chunk=None, always_exchange=True)
+        top1 = big.predict(fb, labb, 1000, k, 0.1, gather="top1")
+        ref_big = ica.knn_predict(fb, big.bank, labb, 1000, k, 0.1)
+        assert torch.equal(top1, ref_big[:, 0]) and torch.equal(big.local_ranking, ref_big)
     finally:
         dist.destroy_process_group()
 
