@@ -27,6 +27,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -59,7 +61,6 @@ def parse():
                          "--bank / G rows, then merge (G candidate blocks) + vote for 1 / G of the queries; no exchange "
                          "(tools/shard_cost.sh: upper bound of the scaling efficiency)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel clock measurement after the timed region")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the query chunks alternate between")
     ap.add_argument("--shard", choices=["rows", "queries"], default="rows",
                     help="rows: the bank is row-sharded (north star, default).  queries: comparison row of SURVEY 8(e) -- "
                          "every rank holds the whole bank and serves a slice of the queries, no candidate exchange")
@@ -117,9 +118,40 @@ def cpu_baseline(feature, bank_rows, labels, args, seconds):
     }
 
 
+def launcher_command(gpus, argv, port=None, python=None):
+    """(command, environment) that starts ``gpus`` ranks of this script, one per GPU, on this node.
+
+    ``python bench.py --gpus N`` outside a torch.distributed launcher (no WORLD_SIZE) is a request for an N-rank
+    job: the parent starts the ranks as FRESH child processes through ``torch.distributed.run`` BEFORE it makes any
+    GPU call of its own (a process that has initialised the GPU must never be replaced or forked into ranks), relays
+    their output and exits with their status.  The reference has no counterpart (models/knn.py:4-21 is single-device)."""
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)                      # the launcher sets them for every rank
+    return cmd, env
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no GPU call has been made in this process (importing torch makes none)
+        cmd, env = launcher_command(args.gpus, sys.argv[1:])
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         f"run `python bench.py --gpus N` (it starts its own ranks) or give torch.distributed.run "
+                         f"--nproc-per-node equal to --gpus")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -127,7 +159,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
         dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
     import image_classification_amd as ica
     from image_classification_amd import _lib
@@ -141,6 +177,8 @@ def main():
     if emu and (world > 1 or not by_rows or N % emu):
         raise SystemExit("--emulate-rank-of is a one-GPU, row-sharded emulation and needs bank rows divisible by G")
     lo, hi = sharded.shard_bounds(N, world, rank) if by_rows else (0, N)
+    # every rank's shard size is known from the partition: no size exchange (and no host read) inside a step
+    shard_sizes = [b - a for a, b in (sharded.shard_bounds(N, world, r) for r in range(world))]
     if emu:
         lo, hi = sharded.shard_bounds(N, emu, 0)                            # rank 0's shard of the G-rank job
     labels = torch.randint(0, C, (N,), generator=torch.Generator(device=device).manual_seed(2), device=device)
@@ -177,7 +215,7 @@ def main():
             return emulated_rank_step()
         if by_rows:
             knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk or None,
-                                     n_streams=args.streams)
+                                     shard_sizes=shard_sizes)
         else:
             knn = sharded.QuerySlicedKnn(bank_rows, compute_dtype=args.dtype, query_chunk=args.query_chunk or 16384)
         top1 = knn.predict(feature, labels, C, k, T, gather="top1")
@@ -258,6 +296,7 @@ def main():
                             f"{C} classes, {args.dtype} MFMA with fp32 accumulate; step = pack + fused sim/top-k"
                             f"{' + RCCL candidate all-to-all + merge' if world > 1 and by_rows else ''} + vote + ranking",
                 "queries": B, "bank_rows": N, "dim": D, "k": k, "classes": C,
+                "ranks": dist.get_world_size() if world > 1 else 1,      # size of the process group that did the work
                 **({"emulated_rank_of": emu, "rank_bank_rows": hi - lo} if emu else {}),
                 "parallelism": (f"bank rows sharded over {world} GPU(s); merge/vote sharded by query slice; top-1 labels all-gathered"
                                 if by_rows else

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -71,6 +72,21 @@ struct ProfScope {
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// A kernel that needs more dynamic LDS than the default limit has that limit raised ONCE per device (bit d of `done`:
+// device ordinal d), not on every call: hipFuncSetAttribute is a driver call on the launch path otherwise.
+template <typename Kernel>
+hipError_t ensure_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev >= 0 && dev < 64 ? (uint64_t)1 << dev : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // --------------------------------------------------------------------------- small kernels
 // pack: float32 source -> compute dtype, K-contiguous rows, zero padded to ld_dst.
@@ -269,7 +285,7 @@ __global__ void scatter_rows_kernel(char *__restrict__ bank, long long K, long l
 // 256 threads = 16 rows x 16 groups; group g folds tiles g, g+16, ... of its row (16 rows of one
 // tile = one coalesced 128-byte read) and columns g*D/16.. of q.key, then the groups meet in LDS.
 // Hand-off of the per-block sums (MI355X_MICROARCH.md, inter-workgroup visibility, counter form): lane 0 stores its
-// block's sum write-through (sc1), waits for the store, then adds to the arrival counter (agent scope); the block
+// block's sum write-through (sc1), waits for the store, then adds to the arrival counter (agent scope, acq_rel); the block
 // whose add returns the last ticket reads every block sum with sc1 loads, adds them in block order (deterministic)
 // and resets the counter.  The counter is zeroed by the preceding similarity kernel (plain store, kernel boundary).
 __global__ __launch_bounds__(256) void moco_combine_kernel(const float *q, const float *key, int b, int D,
@@ -320,8 +336,11 @@ __global__ __launch_bounds__(256) void moco_combine_kernel(const float *q, const
         float bs = 0.f;
         for (int i = 0; i < 16; ++i) bs += s_loss[i];
         __hip_atomic_store(block_sum + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: write-through
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned ticket = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the store has left this CU before the ticket is drawn
+        // acq_rel at agent scope: the arrival RELEASES this block's sum and, in the block that draws the last ticket,
+        // ACQUIRES every other block's -- the ordering the HIP memory model asks for; the sc1 store / sc1 loads and the
+        // drain above are the hardware form the guide prescribes (cdna_hip_programming.md Guideline 16, pitfall 12: keep both)
+        const unsigned ticket = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == gridDim.x - 1) {
             float tot = 0.f;
             for (unsigned i = 0; i < gridDim.x; ++i)
@@ -343,21 +362,13 @@ struct Plan {
     int mask_words;
 };
 
-#ifndef MI_S0_COLS
-#define MI_S0_COLS 2048
-#endif
-constexpr int S0_COLS = MI_S0_COLS;     // dense bootstrap columns
+constexpr int S0_COLS = 2048;           // dense bootstrap columns
 constexpr int BIG_CNT_BYTES = 2 * mi::BIG_SUBLISTS * 128;      // one 128-byte line per counter
 // rows (row >> 2) % 64 == s go to sub-list s: at most 4 * ceil(B_pad / 256) of them
 inline int big_stride(int B_pad) { return 4 * (int)ceil_div(B_pad, 4 * mi::BIG_SUBLISTS); }
 constexpr int STAGE_QUANTUM = 1024;                // filter stages are whole multiples of 4 bank tiles
-#ifndef MI_FIT_MB
-#define MI_FIT_MB 128
-#endif
-#ifndef MI_CAND_BUDGET_GIB
-#define MI_CAND_BUDGET_GIB 8
-#endif
-constexpr int64_t CAND_BUDGET_BYTES = (int64_t)MI_CAND_BUDGET_GIB << 30;   // default size of the candidate buffer
+constexpr int64_t FIT_BYTES = (int64_t)128 << 20;             // bank slice of one launch: stays in the 256 MiB Infinity Cache
+constexpr int64_t CAND_BUDGET_BYTES = (int64_t)8 << 30;       // default size of the candidate buffer
 
 // Workspace layout.  cand_bytes < 0: the default candidate budget; otherwise what the caller gave.
 Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row_bytes = 0)
@@ -379,7 +390,7 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     // 268 MB slice ran 12 % slower than a 134 MB one at C4).
     int64_t launch = cap;
     if (bank_row_bytes > 0) {
-        int64_t fit = (((int64_t)MI_FIT_MB << 20) / bank_row_bytes) / STAGE_QUANTUM * STAGE_QUANTUM;
+        int64_t fit = (FIT_BYTES / bank_row_bytes) / STAGE_QUANTUM * STAGE_QUANTUM;
         if (fit < 8 * STAGE_QUANTUM) fit = 8 * STAGE_QUANTUM;
         if (launch > fit) launch = fit;
     }
@@ -410,15 +421,13 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
 //   then: n = seen / 4, at least one launch: ~k ln 1.25 = 0.22 k candidates per row and stage (within the
 //         wave-per-row merge's 64) and O(log N) refreshes instead of one per launch;
 //   always <= cap: the candidate buffer holds the worst case of one stage (every element passes).
-#ifndef MI_LATE_GROWTH_DIV
-#define MI_LATE_GROWTH_DIV 4
-#endif
+constexpr int LATE_GROWTH_DIV = 4;
 int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t left)      // left: bank rows not filtered yet
 {
     int64_t n = 3 * seen / STAGE_QUANTUM * STAGE_QUANTUM;
     if (n < pl.min_cols) n = pl.min_cols;
     if (n > pl.launch_cols) {
-        n = seen / MI_LATE_GROWTH_DIV / pl.launch_cols * pl.launch_cols;      // whole launches
+        n = seen / LATE_GROWTH_DIV / pl.launch_cols * pl.launch_cols;      // whole launches
         if (n < pl.launch_cols) n = pl.launch_cols;
     }
     if (n > pl.cap) n = pl.cap;
@@ -837,8 +846,10 @@ int mi_knn_vote(const float *val, const int64_t *idx, const int64_t *labels, int
         return MI_OK;
     }
     const size_t dyn = (size_t)round_up((int64_t)classes * 2, 16);
-    if (dyn > 48 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)mi::vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    if (dyn > 48 * 1024) {
+        static std::atomic<uint64_t> done{0};
+        HIP_CHECK(ensure_dynamic_lds(mi::vote_kernel, (size_t)MI_MAX_CLASSES * 2, done));      // the largest it can ask for
+    }
     hipLaunchKernelGGL(mi::vote_kernel, dim3((unsigned)B), dim3(mi::VOTE_THREADS), dyn, (hipStream_t)stream, vp);
     HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -902,9 +913,7 @@ int mi_bank_scatter(void *bank, int64_t K, int64_t row_bytes, const int64_t *ind
 
 // ------------------------------------------------------------------ MoCo queue logits
 namespace {
-#ifndef MI_MOCO_BWD_WGS
-#define MI_MOCO_BWD_WGS 512
-#endif
+constexpr int MOCO_BWD_WGS = 512;       // workgroups of the backward (two waves per SIMD)
 struct MocoPlan { int b_pad, ntiles, lse_ld; size_t off_part, off_rowloss, fwd_total; int nslices, rows_per_slice; size_t bwd_total, total; };
 MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
 {
@@ -915,10 +924,10 @@ MocoPlan moco_plan(int64_t b, int64_t K, int64_t D)
     m.off_part = 0;
     m.off_rowloss = (size_t)round_up((int64_t)m.ntiles * m.lse_ld * 8, 256);      // the arrival counter (own line) + per-block loss sums
     m.fwd_total = m.off_rowloss + 256 + (size_t)round_up((int64_t)ceil_div(b, 16) * 4, 256);
-    // backward: ~MI_MOCO_BWD_WGS workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
+    // backward: ~MOCO_BWD_WGS workgroups = (64-row query tiles) x (queue slices); one [b, D] partial per slice
     const int64_t qtiles = ceil_div(b, mi::MB_ROWS);
     const int64_t ktiles = ceil_div(K, mi::MB_ROWS);
-    int64_t ns = ceil_div(MI_MOCO_BWD_WGS, qtiles);
+    int64_t ns = ceil_div(MOCO_BWD_WGS, qtiles);
     if (ns > ktiles) ns = ktiles;
     if (ns < 1) ns = 1;
     m.rows_per_slice = (int)(ceil_div(ktiles, ns) * mi::MB_ROWS);
@@ -1013,7 +1022,8 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
         const size_t lds = mi::attend_lds_bytes((int)D, (int)D, false);
 #define MI_LAUNCH_BWD(D64)                                                                                       \
         do {                                                                                                    \
-            HIP_CHECK(hipFuncSetAttribute((const void *)mi::attend_kernel<D64, D64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            static std::atomic<uint64_t> done{0};      /* lds is a constant of the instantiation */                \
+            HIP_CHECK(ensure_dynamic_lds(mi::attend_kernel<D64, D64, false>, lds, done));                       \
             hipLaunchKernelGGL((mi::attend_kernel<D64, D64, false>), grid, dim3(mi::MB_THREADS), lds, s, bp);   \
         } while (0)
         switch ((int)(D / 64)) {
@@ -1034,16 +1044,17 @@ int mi_moco_bwd(const float *q, const float *key, const float *queue, int64_t b,
 // ------------------------------------------------------------------ CoMatch soft-kNN smoothing
 extern "C++" {
 namespace {
-#ifndef MI_SOFT_WGS
-#define MI_SOFT_WGS 256
-#endif
+constexpr int SOFT_WGS = 256;
 struct SoftPlan { int V, nslices, rows_per_slice; size_t total; };
-SoftPlan soft_plan(int64_t b, int64_t K, int64_t C)
+SoftPlan soft_plan(int64_t b, int64_t K, int64_t D, int64_t C)
 {
     SoftPlan sp{};
     sp.V = (int)round_up(C + 1, 64);                       // + the row-sum column
+    // attend_kernel<3, 3, true> and <4, 3, true> do not fit the register file (124 / 240 bytes of scratch per lane at
+    // 256 VGPR + 256 AGPR): 128 <= C <= 190 with D >= 192 runs the 256-column instantiation, which does (zero columns)
+    if (sp.V == 192 && D >= 192) sp.V = 256;
     const int64_t qtiles = ceil_div(b, mi::MB_ROWS), ktiles = ceil_div(K, mi::MB_ROWS);
-    int64_t ns = ceil_div(MI_SOFT_WGS, qtiles);
+    int64_t ns = ceil_div(SOFT_WGS, qtiles);
     if (ns > ktiles) ns = ktiles;
     if (ns < 1) ns = 1;
     sp.rows_per_slice = (int)(ceil_div(ktiles, ns) * mi::MB_ROWS);
@@ -1055,7 +1066,8 @@ SoftPlan soft_plan(int64_t b, int64_t K, int64_t C)
 template <int D64, int V64>
 hipError_t launch_soft(const mi::AttendParams &ap, dim3 grid, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)mi::attend_kernel<D64, V64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<uint64_t> done{0};              // lds is a constant of the instantiation
+    hipError_t e = ensure_dynamic_lds(mi::attend_kernel<D64, V64, true>, lds, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((mi::attend_kernel<D64, V64, true>), grid, dim3(mi::MB_THREADS), lds, s, ap);
     return hipGetLastError();
@@ -1066,7 +1078,9 @@ hipError_t launch_soft_v(int v64, const mi::AttendParams &ap, dim3 grid, size_t 
     switch (v64) {
     case 1: return launch_soft<D64, 1>(ap, grid, lds, s);
     case 2: return launch_soft<D64, 2>(ap, grid, lds, s);
-    case 3: return launch_soft<D64, 3>(ap, grid, lds, s);
+    case 3:
+        if constexpr (D64 < 3) return launch_soft<D64, 3>(ap, grid, lds, s);
+        else return hipErrorInvalidValue;              // never planned (soft_plan pads V to 256): those two instantiations spill
     default: return launch_soft<D64, 4>(ap, grid, lds, s);
     }
 }
@@ -1076,7 +1090,7 @@ hipError_t launch_soft_v(int v64, const mi::AttendParams &ap, dim3 grid, size_t 
 size_t mi_soft_knn_workspace_bytes(int64_t b, int64_t K, int64_t D, int64_t C)
 {
     if (b <= 0 || K <= 0 || D <= 0 || C <= 0 || C > 255) return 0;
-    return soft_plan(b, K, C).total;
+    return soft_plan(b, K, D, C).total;
 }
 
 int mi_soft_knn(const float *feature, const float *bank_feature, const float *bank_prob, const float *probs_in,
@@ -1089,7 +1103,7 @@ int mi_soft_knn(const float *feature, const float *bank_feature, const float *ba
     if (C < 1 || C > 255) return fail(MI_ERR_UNSUPPORTED, "mi_soft_knn: C=%lld outside [1, 255]", (long long)C);
     if (!(temperature > 0.f)) return fail(MI_ERR_ARG, "mi_soft_knn: temperature must be positive");
     if (((uintptr_t)feature | (uintptr_t)bank_feature | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_soft_knn: feature, bank_feature, workspace must be 16-byte aligned");
-    const SoftPlan sp = soft_plan(b, K, C);
+    const SoftPlan sp = soft_plan(b, K, D, C);
     if (workspace_bytes < sp.total) return fail(MI_ERR_WORKSPACE, "mi_soft_knn: workspace %zu < required %zu", workspace_bytes, sp.total);
     const size_t lds = mi::attend_lds_bytes((int)D, sp.V, true);
     if (lds > 160 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_soft_knn: D=%lld with C=%lld needs %zu bytes of LDS (> 160 KiB)", (long long)D, (long long)C, lds);

@@ -101,15 +101,8 @@ __device__ __forceinline__ float row16_sum(float v)
 
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
-#ifndef MI_L2_PREFETCH
-#define MI_L2_PREFETCH 1
-#endif
-#ifndef MI_PF_DIST
-#define MI_PF_DIST 2
-#endif
-#ifndef MI_PF_POS
-#define MI_PF_POS 4
-#endif
+// L2 prefetch schedule (measured): touch the lines of K-step t + PF_DIST after MFMA group PF_POS of step t
+constexpr int PF_DIST = 2, PF_POS = 4;
 
 template <int DT, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
@@ -186,7 +179,6 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_pair(i, 0, 0);
 
-#if MI_L2_PREFETCH
     // ---- L2 prefetch.  The 32 workgroups of an XCD patch stream the same 8 + 4 operand tiles, so 19 % of the
     // DMA requests -- the first touch of every line in this XCD -- miss the L2 and take the Infinity-Cache
     // latency, which a two-buffer pipeline cannot hide (one K-step of lead).  Each workgroup therefore touches
@@ -224,9 +216,6 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
             : [l] "s"(pf_lds), [a] "v"(pf_src + (long long)t * KSTEP_BYTES)
             : "memory");
     };
-#else
-    auto prefetch = [&](int) {};
-#endif
 
     // ---- MFMA operand read offsets.  Lane reads row (lane & 15) of a 16-row block; K chunk
     // (lane >> 4) [+4 for the second half of the K-step]; swizzle term depends on the lane only.
@@ -278,7 +267,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     if (pr < 4) stage_pair(pr, t + 1, nbuf);
                 }
                 if constexpr (PF) {
-                    if (pr == MI_PF_POS) prefetch(t + MI_PF_DIST);
+                    if (pr == PF_POS) prefetch(t + PF_DIST);
                 }
                 if (pr < 7) {
                     const int ns = (pr + 1) >> 2, np = (pr + 1) & 3;
@@ -330,7 +319,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                     if (kk < 4) stage_pair(kk, t + 1, nbuf);
                 }
                 if constexpr (PF) {
-                    if (kk == 4) prefetch(t + MI_PF_DIST);
+                    if (kk == PF_POS) prefetch(t + PF_DIST);
                 }
                 if (kk < 7) {
                     const int co = (((kk + 1) ^ sw) * 16) + lq * 4;
@@ -365,15 +354,10 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 
     stage_wait(std::false_type{});                   // the first operand stage (issued at the top) and the thresholds
     __syncthreads();
-#if MI_L2_PREFETCH
     for (int t = 0; t + 2 < p.ksteps; ++t) kstep(t, std::true_type{}, std::true_type{});
     if (p.ksteps > 1) kstep(p.ksteps - 2, std::true_type{}, std::false_type{});
     kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the last touches have landed before LDS is reused
-#else
-    for (int t = 0; t + 1 < p.ksteps; ++t) kstep(t, std::true_type{}, std::false_type{});
-    kstep(p.ksteps - 1, std::false_type{}, std::false_type{});
-#endif
 
     // ---- epilogue.  C/D map of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int row_base = q0 + wm * 128 + lq * 4;          // + i*16 + reg

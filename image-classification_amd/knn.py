@@ -16,8 +16,9 @@ There is no CPU path here: tensors must live on a HIP device and the library mus
 from __future__ import annotations
 
 import os
+import weakref
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -178,6 +179,30 @@ class BankBuilder:
         return BankIndex(PackedRows(self.data, self.n_rows, self.dim, self.code), self.idx_base)
 
 
+def _topk_workspace(L, B: int, N: int, k: int, dev) -> Tuple[torch.Tensor, int]:
+    """Candidate workspace of one fused top-k call.  The result never depends on its size (only the number of filter
+    stages does), so when the preferred budget (``MI_KNN_WORKSPACE_GIB``, 16 GiB of the 288 GB) does not fit beside
+    what a training job already holds, smaller plans are tried -- the library's default 8 GiB plan, then 1 GiB, then
+    the minimum (one 2048-column stage) -- before the allocation failure is allowed to propagate."""
+    b_pad = -(-B // 256) * 256
+    minimum = 2048 * (b_pad * 8 + b_pad // 128 + 1) + 1024 + 4 * b_pad
+    budgets, seen = [], set()
+    for budget in (WORKSPACE_GIB << 30, 8 << 30, 1 << 30, minimum):
+        nbytes = int(L.mi_knn_topk_workspace_bytes_for_budget(B, N, k, max(budget, minimum)))
+        if nbytes == 0:
+            raise ValueError(f"unsupported kNN shape B={B} N={N} k={k} (1 <= k <= {_lib.MI_MAX_K})")
+        if nbytes not in seen:
+            seen.add(nbytes)
+            budgets.append(nbytes)
+    for i, nbytes in enumerate(budgets):
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+        except torch.OutOfMemoryError:
+            if i + 1 == len(budgets):
+                raise
+    raise AssertionError("unreachable")
+
+
 def knn_topk(feature: torch.Tensor, bank: BankIndex, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Fused similarity + top-k (``models/knn.py:6,8``) -> (values [B, k] f32 desc, indices [B, k] i64).
 
@@ -194,10 +219,7 @@ def knn_topk(feature: torch.Tensor, bank: BankIndex, k: int) -> Tuple[torch.Tens
     L = _lib.lib()
     B = q.rows
     dev = feature.device
-    ws_bytes = int(L.mi_knn_topk_workspace_bytes_for_budget(B, bank.n, k, WORKSPACE_GIB << 30))
-    if ws_bytes == 0:
-        raise ValueError(f"unsupported kNN shape B={B} N={bank.n} k={k} (1 <= k <= {_lib.MI_MAX_K})")
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws, ws_bytes = _topk_workspace(L, B, bank.n, k, dev)
     val = torch.empty((B, k), dtype=torch.float32, device=dev)
     idx = torch.empty((B, k), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
@@ -248,13 +270,29 @@ def knn_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor, k: int) -> Tuple[t
     return val, idx
 
 
+# label tensors already validated: id(tensor) -> (weak reference, tensor version, min label, max label)
+_LABELS_OK: Dict[int, tuple] = {}
+
+
 def check_labels(feature_labels: torch.Tensor, classes: int) -> None:
     """The reference raises (index error in ``scatter``, ``models/knn.py:16``) when a bank label is outside
     ``[0, classes)``; the vote kernel would silently give such a neighbour no vote.  One fused min/max over the labels
-    and one host read; skipped while the stream is being captured into a HIP graph (no host read is possible there)."""
-    if feature_labels.numel() == 0 or (feature_labels.is_cuda and torch.cuda.is_current_stream_capturing()):
+    and one host read -- ONCE per label tensor: the (min, max) of a tensor object is remembered until the tensor is
+    modified in place (its version counter) or dies, so a caller that votes chunk by chunk, or every monitor pass over
+    the same ``feature_labels``, pays the pass and the host synchronisation once.  Skipped while the stream is being
+    captured into a HIP graph (no host read is possible there)."""
+    if feature_labels.numel() == 0:
         return
-    lo, hi = (int(v) for v in torch.aminmax(feature_labels))
+    ent = _LABELS_OK.get(id(feature_labels))
+    if ent is not None and ent[0]() is feature_labels and ent[1] == feature_labels._version:
+        lo, hi = ent[2], ent[3]
+    else:
+        if feature_labels.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        lo, hi = (int(v) for v in torch.aminmax(feature_labels))
+        if len(_LABELS_OK) >= 64:
+            _LABELS_OK.clear()
+        _LABELS_OK[id(feature_labels)] = (weakref.ref(feature_labels), feature_labels._version, lo, hi)
     if lo < 0 or hi >= int(classes):
         raise IndexError(f"feature_labels span [{lo}, {hi}] but classes={int(classes)}: every label must lie in "
                          f"[0, classes) (models/knn.py:16 raises here too)")
@@ -269,11 +307,11 @@ def knn_vote(sim_weight: torch.Tensor, sim_indices: torch.Tensor, feature_labels
     _require_device(sim_weight, "sim_weight")
     dev = sim_weight.device
     B, k = sim_weight.shape
-    labels = feature_labels.to(device=dev, dtype=torch.int64).contiguous()
-    if labels.dim() != 1:
+    if feature_labels.dim() != 1:
         raise ValueError("feature_labels must be 1-D")
     if check:
-        check_labels(labels, classes)
+        check_labels(feature_labels, classes)           # the caller's tensor object: validated once (see check_labels)
+    labels = feature_labels.to(device=dev, dtype=torch.int64).contiguous()
     sim_weight = sim_weight.contiguous()
     sim_indices = sim_indices.contiguous()
     rank = torch.empty((B, int(classes)), dtype=torch.int64, device=dev)

@@ -88,6 +88,21 @@ def protect_rows(bank: torch.Tensor, lo: int, n: int) -> Optional[torch.Tensor]:
     return stash
 
 
+# Scratch of mi_moco_fwd / mi_moco_bwd (tile partials), cached per (device, stream): both calls use it as pure scratch
+# (nothing a forward writes there is read by a backward), every use is ordered by the stream, so ONE buffer serves every
+# loss on that stream instead of a fresh torch.empty per call (the forward is ~45 us of kernels: allocations show).
+_SCRATCH: Dict[tuple, torch.Tensor] = {}
+
+
+def _scratch(dev: torch.device, stream_ptr: int, nbytes: int) -> torch.Tensor:
+    key = (dev.index, stream_ptr)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _SCRATCH[key] = buf
+    return buf
+
+
 class _MocoQueueLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, query, key, memory, temperature):
@@ -105,17 +120,17 @@ class _MocoQueueLoss(torch.autograd.Function):
             # (mi_moco_bwd) is built for D % 64 == 0, D <= 256 (the reference's feature_dim is 128)
             raise NotImplementedError(f"the backward w.r.t. query needs D % 64 == 0 and D <= 256, got D={D}")
         ws_bytes = int(L.mi_moco_workspace_bytes(b, K, D))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        lse = torch.empty(b, dtype=torch.float32, device=dev)
-        lpos = torch.empty(b, dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        stream = _lib.stream_ptr(dev)
+        ws = _scratch(dev, stream, ws_bytes)
+        out = torch.empty(2 * b + 1, dtype=torch.float32, device=dev)      # lse | lpos | loss: one allocation
+        lse, lpos, loss = out[:b], out[b:2 * b], out[2 * b:]
         with torch.cuda.device(dev):
             _lib.check(L.mi_moco_fwd(q.data_ptr(), k.data_ptr(), memory.data_ptr(), b, K, D, float(temperature),
-                                     lse.data_ptr(), lpos.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws_bytes,
-                                     _lib.stream_ptr(dev)), "mi_moco_fwd")
+                                     lse.data_ptr(), lpos.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     stream), "mi_moco_fwd")
         ctx.save_for_backward(q, k, lse, lpos)
         ctx.temperature = float(temperature)
-        ctx.ws = ws if need_dq else None
+        ctx.ws_bytes = ws_bytes if need_dq else 0
         ctx.pending = None
         if need_dq:
             # only the query gradient reads the queue again: pushes must protect its rows until backward has run
@@ -141,6 +156,8 @@ class _MocoQueueLoss(torch.autograd.Function):
             memory = pend.snapshot if pend.snapshot is not None else pend.memory
             K = memory.shape[0]
             patch = pend.patch_rows
+        stream = _lib.stream_ptr(dev)
+        ws = _scratch(dev, stream, ctx.ws_bytes) if need_dq else None      # the stream backward runs on (autograd replays the forward's)
         with torch.cuda.device(dev):
             _lib.check(L.mi_moco_bwd(q.data_ptr(), k.data_ptr(), memory.data_ptr() if need_dq else None, b, K, D,
                                      ctx.temperature, lse.data_ptr(), lpos.data_ptr(), g.data_ptr(),
@@ -148,8 +165,8 @@ class _MocoQueueLoss(torch.autograd.Function):
                                      patch.data_ptr() if patch is not None else None,
                                      pend.patch_lo if patch is not None else 0,
                                      patch.shape[0] if patch is not None else 0,
-                                     ctx.ws.data_ptr() if need_dq else None, ctx.ws.numel() if need_dq else 0,
-                                     _lib.stream_ptr(dev)), "mi_moco_bwd")
+                                     ws.data_ptr() if need_dq else None, ws.numel() if need_dq else 0,
+                                     stream), "mi_moco_bwd")
         if pend is not None:
             # backward has run: pushes no longer need to protect rows for this loss
             refs = _PENDING.get(pend.memory.data_ptr())

@@ -25,7 +25,6 @@ gloo; the default ops are the HIP kernels and fail loudly without the library or
 """
 from __future__ import annotations
 
-import contextlib
 from typing import Optional, Tuple
 
 import torch
@@ -126,7 +125,8 @@ class ShardedKnn:
     """
 
     def __init__(self, bank_rows_local: torch.Tensor, idx_base: int, group=None, ops=None,
-                 compute_dtype=None, query_chunk: Optional[int] = 8192, n_streams: int = 1, always_exchange: bool = False):
+                 compute_dtype=None, query_chunk: Optional[int] = 8192, always_exchange: bool = False,
+                 shard_sizes=None):
         self.group = group
         self.world = dist.get_world_size(group) if _dist_on() else 1
         self.rank = dist.get_rank(group) if _dist_on() else 0
@@ -135,16 +135,22 @@ class ShardedKnn:
         self.bank = self.ops.build_bank(bank_rows_local, self.idx_base)
         self.n_local = int(self.ops.bank_rows(self.bank))
         self.query_chunk = int(query_chunk) if query_chunk else auto_query_chunk(self.n_local)      # None / 0: by shard size
-        self.n_streams = max(1, int(n_streams))
         # always_exchange: a one-rank group still goes through the collectives and the merge (lets a one-GPU box
         # run the RCCL branches); otherwise a single rank skips them
         self.solo = self.world == 1 and not (always_exchange and _dist_on())
-        sizes = [self.n_local]
-        if not self.solo:
+        # shard_sizes: rows of every rank's shard, when the caller knows the partition (shard_bounds): no collective
+        # and no host read in the constructor.  Otherwise the sizes are all-gathered once, here.
+        if shard_sizes is not None:
+            sizes = [int(v) for v in shard_sizes]
+            if len(sizes) != (1 if self.solo else self.world) or sizes[self.rank] != self.n_local:
+                raise ValueError(f"shard_sizes {sizes} does not describe {self.world} rank(s) with {self.n_local} rows on rank {self.rank}")
+        elif self.solo:
+            sizes = [self.n_local]
+        else:
             t = torch.tensor([self.n_local], dtype=torch.int64, device=bank_rows_local.device)
-            out = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(out, t, group=group)
-            sizes = [int(o.item()) for o in out]
+            out = torch.empty((self.world,), dtype=torch.int64, device=bank_rows_local.device)
+            _all_gather(group, out, t)
+            sizes = [int(v) for v in out.tolist()]                 # one host read
         self.shard_sizes = sizes
         self.n_total = sum(sizes)
 
@@ -172,42 +178,22 @@ class ShardedKnn:
 
     @torch.no_grad()
     def topk(self, feature: torch.Tensor, k: int):
-        """Global top-k (values, global rows) for every query, identical on every rank.
-
-        Query chunks alternate between ``n_streams`` HIP streams: the threshold-refresh kernels,
-        launch tails, exchange and merge of one chunk run beside the next chunk's GEMM."""
+        """Global top-k (values, global rows) for every query, identical on every rank.  Chunk i's all-gather is
+        issued asynchronously and runs beside chunk i+1's GEMM."""
         if k > self.n_total:
             raise RuntimeError(f"selected index k out of range (k={k} > N={self.n_total})")
         if self.n_total >= 2 ** 32:
             raise ValueError("mi_knn_merge keys global rows as 32-bit values: N must be < 2^32")
-        B = feature.shape[0]
-        starts = chunk_bounds(B, self.query_chunk)
-        side = _side_streams(feature.device, self.n_streams) if (feature.is_cuda and len(starts) > 1) else None
-        main = torch.cuda.current_stream(feature.device) if side else None
-        outs = [None] * len(starts)
-        pending = None                                   # (chunk number, exchange in flight)
-
-        def on_stream(i):
-            return torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()
-
-        for i, (s, e) in enumerate(starts):
-            if side and i < len(side):
-                side[i].wait_stream(main)                # inputs were produced on the caller's stream
-            with on_stream(i):
-                val, idx = self._local_candidates(feature[s:e], k)
-                nxt = self._exchange(val, idx)           # chunk i's all-gather runs beside the next chunk's GEMM
+        starts = chunk_bounds(feature.shape[0], self.query_chunk)
+        outs = []
+        pending = None                                   # exchange in flight
+        for s, e in starts:
+            val, idx = self._local_candidates(feature[s:e], k)
+            nxt = self._exchange(val, idx)
             if pending is not None:
-                with on_stream(pending[0]):
-                    outs[pending[0]] = self._finish(pending[1], k)
-            pending = (i, nxt)
-        with on_stream(pending[0]):
-            outs[pending[0]] = self._finish(pending[1], k)
-        if side:
-            for st in side[:len(starts)]:
-                main.wait_stream(st)
-            for v, ix in outs:
-                v.record_stream(main)
-                ix.record_stream(main)
+                outs.append(self._finish(pending, k))
+            pending = nxt
+        outs.append(self._finish(pending, k))
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 
     def _finish(self, pending, k):
@@ -274,37 +260,18 @@ class ShardedKnn:
             self.ops.check_labels(feature_labels, classes)
         B, G = feature.shape[0], self.world
         starts = chunk_bounds(B, self.query_chunk)
-        slices, rows = [None] * len(starts), []
-        # n_streams > 1: query chunks alternate between side streams, so the threshold refreshes, launch gaps,
-        # exchange, merge and vote of one chunk run beside the other chunk's GEMM (pays when the shard is small)
-        side = _side_streams(feature.device, self.n_streams) if (feature.is_cuda and self.n_streams > 1
-                                                                  and len(starts) > 1) else None
-        main = torch.cuda.current_stream(feature.device) if side else None
-
-        def on_stream(i):
-            return torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext()
-
-        pending = None                                   # (chunk number, exchange in flight)
-        for i, (s, e) in enumerate(starts):
-            if side and i < len(side):
-                side[i].wait_stream(main)                # inputs were produced on the caller's stream
+        slices, rows = [], []
+        pending = None                                   # exchange in flight
+        for s, e in starts:
             f = feature[s:e]
-            with on_stream(i):
-                val, idx = self._local_candidates(f, k)
-                nxt = self._to_owners(val, idx)          # chunk i's exchange runs beside the next chunk's GEMM
+            val, idx = self._local_candidates(f, k)
+            nxt = self._to_owners(val, idx)              # chunk i's exchange runs beside the next chunk's GEMM
             if pending is not None:
-                with on_stream(pending[0]):
-                    slices[pending[0]] = self._own_slice(pending[1], k, feature_labels, classes, knn_t)
-            pending = (i, nxt)
+                slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
+            pending = nxt
             lo, hi = shard_bounds(f.shape[0], G, self.rank)
             rows.append(torch.arange(s + lo, s + hi, device=feature.device))
-        with on_stream(pending[0]):
-            slices[pending[0]] = self._own_slice(pending[1], k, feature_labels, classes, knn_t)
-        if side:
-            for st in side[:len(starts)]:
-                main.wait_stream(st)
-            for sl in slices:
-                sl.record_stream(main)
+        slices.append(self._own_slice(pending, k, feature_labels, classes, knn_t))
         self.local_rows = torch.cat(rows)
         self.local_ranking = torch.cat(slices, 0)
         if self.solo:
@@ -374,17 +341,6 @@ class QuerySlicedKnn:
         allr = allr.view(G, longest, width)
         out = torch.cat([allr[j, :shard_bounds(B, G, j)[1] - shard_bounds(B, G, j)[0]] for j in range(G)], 0)
         return out if gather == "full" else out[:, 0].contiguous()
-
-
-_SIDE = {}
-
-
-def _side_streams(device, n):
-    """Side streams are created once per device and reused (creation synchronises the device)."""
-    key = (torch.device(device).index, n)
-    if key not in _SIDE:
-        _SIDE[key] = [torch.cuda.Stream(device) for _ in range(n)]
-    return _SIDE[key]
 
 
 def _dist_on() -> bool:

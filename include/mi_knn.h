@@ -13,7 +13,15 @@
  *     all work is enqueued on it, nothing synchronises the host;
  *   - every entry point returns 0 (MI_OK) or a negative MI_ERR_* code; the message of the last
  *     error on the calling thread is available from mi_last_error();
- *   - re-entrant: no global mutable state except that thread-local error string.
+ *   - re-entrant, with three documented exceptions.  The entry points keep no state between calls beyond the
+ *     thread-local error string, so calls from several host threads / on several streams are independent, EXCEPT:
+ *       (1) mi_knn_topk_static works in ONE per-GPU static scratch array: it is not re-entrant per GPU -- calls
+ *           that overlap on one GPU (two streams, two threads) race on that array; keep them on one stream;
+ *       (2) mi_profile_enable / mi_profile_collect / mi_profile_clock are process-wide DEBUG switches behind
+ *           mutexes: while a stamp buffer is registered EVERY filter launch of the process runs the stamped
+ *           kernel instantiation, while profiling is on every launch is bracketed by events;
+ *       (3) the first call of a kernel that needs more than the default dynamic LDS raises that kernel's limit
+ *           once per process (std::call_once), not per call.
  */
 #ifndef MI_KNN_H
 #define MI_KNN_H

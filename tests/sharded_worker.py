@@ -62,6 +62,15 @@ def main(rank, world, port, use_gpu, out_dir):
         ops = None if use_gpu else OracleOps()
         knn = sh.ShardedKnn(torch.from_numpy(x[lo:hi]).to(dev), lo, ops=ops, compute_dtype="fp32", query_chunk=16)
         assert knn.n_total == x.shape[0] and knn.shard_sizes[rank] == hi - lo
+        # a caller that knows the partition passes the shard sizes: the constructor then runs no collective
+        sizes = [b - a for a, b in (sh.shard_bounds(x.shape[0], world, r) for r in range(world))]
+        knn2 = sh.ShardedKnn(torch.from_numpy(x[lo:hi]).to(dev), lo, ops=ops, compute_dtype="fp32", query_chunk=16, shard_sizes=sizes)
+        assert knn2.shard_sizes == knn.shard_sizes and knn2.n_total == knn.n_total
+        try:
+            sh.ShardedKnn(torch.from_numpy(x[lo:hi]).to(dev), lo, ops=ops, compute_dtype="fp32", shard_sizes=[1] * world)
+            raise AssertionError("wrong shard_sizes accepted")
+        except ValueError:
+            pass
         val, idx = knn.topk(torch.from_numpy(f).to(dev), k)
         pred = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T)
         top1 = knn.predict(torch.from_numpy(f).to(dev), torch.from_numpy(lab).to(dev), C, k, T, gather="top1")

@@ -1,0 +1,53 @@
+"""bench.py --gpus N must run N ranks: the launcher's command / environment, the world-size check, and one real
+start of two ranks (which stop at once here: no GPU is visible to them).  CPU only."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_launcher_command_and_env(n, monkeypatch):
+    monkeypatch.setenv("RANK", "3")                      # stale launcher variables must not leak into the ranks
+    monkeypatch.setenv("WORLD_SIZE", "5")
+    b = _bench()
+    argv = ["--gpus", str(n), "--steps", "20", "--warmup", "5"]
+    cmd, env = b.launcher_command(n, argv, port=29731, python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and f"--nproc-per-node={n}" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29731"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                           # the ranks get the caller's flags unchanged
+    assert "RANK" not in env and "WORLD_SIZE" not in env and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    cmd2, _ = b.launcher_command(n, argv)                # a free port is picked when none is given
+    assert 1024 < int(cmd2[cmd2.index("--master-port") + 1]) < 65536
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "WORLD_SIZE=2" in r.stderr
+
+
+def test_gpus_2_starts_two_ranks_and_relays_their_status():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself.  With no GPU visible each rank
+    stops with bench.py's own message, and the parent exits non-zero: both facts prove the ranks were started."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]

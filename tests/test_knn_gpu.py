@@ -1,5 +1,7 @@
 """GPU parity tests (run on the MI355X box: ``pytest -m gpu``).  Everything goes through the C ABI
 (``libmi_knn.so``) via the package's ctypes binding; the oracle is only the checker."""
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -259,13 +261,13 @@ def test_index_base_and_merge_equals_unsharded(ica):
         assert np.array_equal(v.cpu().numpy(), vo) and np.array_equal(i.cpu().numpy(), io)
 
 
-@pytest.mark.parametrize("streams", [1, 2, 3])
-def test_chunked_multi_stream_driver_equals_single_call(ica, streams):
-    """ShardedKnn (world 1): query chunks alternating between side streams give the single-call result bit for bit."""
+@pytest.mark.parametrize("chunk", [256, 300, 4096])
+def test_chunked_driver_equals_single_call(ica, chunk):
+    """ShardedKnn (world 1): the query-chunked driver gives the single-call result bit for bit."""
     f, x, lab = _rand_case(1100, 12000, 64, 10, 21)
     k = 200
     v_ref, i_ref = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "bf16"), k)
-    knn = ica.sharded.ShardedKnn(dev(x), 0, compute_dtype="bf16", query_chunk=256, n_streams=streams)
+    knn = ica.sharded.ShardedKnn(dev(x), 0, compute_dtype="bf16", query_chunk=chunk, shard_sizes=[12000])
     v, i = knn.topk(dev(f), k)
     assert torch.equal(v, v_ref) and torch.equal(i, i_ref)
     pred = knn.predict(dev(f), dev(lab), 10, k, 0.1)
@@ -313,6 +315,46 @@ def test_labels_outside_the_class_range_raise_like_the_reference(ica):
     with pytest.raises(IndexError):
         ica.sharded.ShardedKnn(dev(x), 0, compute_dtype="fp32").predict(dev(f), dev(bad), 5, 20, 0.1)
     assert tuple(ica.knn_predict(dev(f), dev(x.T.copy()), dev(lab), 5, 20, 0.1).shape) == (9, 5)
+
+
+def test_label_range_is_validated_once_per_tensor_and_again_after_an_in_place_change(ica, monkeypatch):
+    """check_labels remembers a validated label tensor (no host read per vote) until it is modified in place."""
+    f, x, lab = _rand_case(9, 500, 32, 5, 4)
+    labels, bank = dev(lab), ica.BankIndex.from_rows(dev(x), "fp32")
+    calls = []
+    real = torch.aminmax
+    monkeypatch.setattr(torch, "aminmax", lambda t: (calls.append(1), real(t))[1])
+    for _ in range(3):
+        ica.knn_predict(dev(f), bank, labels, 5, 20, 0.1)
+    assert len(calls) == 1                                   # one pass + host read for three monitor passes
+    with pytest.raises(IndexError, match="classes=4"):       # the remembered range still answers a smaller class count
+        ica.knn_predict(dev(f), bank, labels, 4, 20, 0.1)
+    assert len(calls) == 1
+    labels[3] = 7                                            # in-place change: the version counter moves
+    with pytest.raises(IndexError, match="classes=5"):
+        ica.knn_predict(dev(f), bank, labels, 5, 20, 0.1)
+    assert len(calls) == 2
+
+
+def test_workspace_allocation_falls_back_to_smaller_plans(ica, monkeypatch):
+    """A failed allocation of the preferred candidate workspace retries with smaller plans; the result is the same."""
+    f, x, lab = _rand_case(300, 40000, 64, 10, 5)
+    bank = ica.BankIndex.from_rows(dev(x), "fp32")
+    v_ref, i_ref = ica.knn_topk(dev(f), bank, 50)
+    real, sizes = torch.empty, []
+
+    def failing_empty(*a, **kw):
+        if kw.get("dtype") is torch.uint8 and isinstance(a[0], int) and a[0] > (64 << 20):
+            sizes.append(a[0])
+            raise torch.OutOfMemoryError("simulated: HBM held by the training job")
+        return real(*a, **kw)
+
+    knn_mod = sys.modules[ica.knn_topk.__module__]
+    monkeypatch.setattr(knn_mod.torch, "empty", failing_empty)
+    v, i = ica.knn_topk(dev(f), bank, 50)
+    monkeypatch.undo()
+    assert sizes and sizes == sorted(sizes, reverse=True)    # larger plans were tried first and refused
+    assert torch.equal(v, v_ref) and torch.equal(i, i_ref)
 
 
 def test_deterministic_across_runs(ica):
