@@ -951,21 +951,49 @@ __device__ __forceinline__ unsigned long long bag_select_kth(const unsigned long
            (unsigned)__builtin_amdgcn_readlane((int)flo, src);
 }
 
-// First threshold from the bootstrap SAMPLE (mi_knn_topk, sampled mode): tau[row] = k-th largest of the row's NV * 64
-// dense similarities (duplicates count, NaNs do not), left at -inf when fewer than k are real.  One wave per row, the
-// values in registers (NV per lane), the same ballot radix select on the order-preserving word; nothing else is
-// kept -- the sampled bank rows go through the filter like every other row.
+// sum over the 64 lanes (result wave-uniform): xor-butterfly inside each 16-lane DPP row, then the four rows by readlane
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+    v += dpp_u32<0xB1>(v); v += dpp_u32<0x4E>(v); v += dpp_u32<0x141>(v); v += dpp_u32<0x140>(v);
+    return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) +
+                      __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+}
+
+// 32 x 32 bit-matrix transpose in registers (the five-stage butterfly): afterwards word i holds bit (31 - i) of every
+// input word, input word c at bit position (31 - c).
+__device__ __forceinline__ void bit_transpose32(unsigned (&a)[32])
+{
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int j = 16 >> st;
+        const unsigned m = st == 0 ? 0x0000FFFFu : st == 1 ? 0x00FF00FFu : st == 2 ? 0x0F0F0F0Fu : st == 3 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k & j) continue;
+            const unsigned t = (a[k] ^ (a[k + j] >> j)) & m;
+            a[k] ^= t;
+            a[k + j] ^= t << j;
+        }
+    }
+}
+
+// First threshold from the bootstrap SAMPLE (mi_knn_topk, sampled mode): tau[row] = k-th largest of the row's 2048
+// dense similarities (duplicates count, NaNs do not), left at -inf when fewer than k are real.  One wave per row, 32
+// values per lane in registers; nothing else is kept -- the sampled bank rows go through the filter like every other row.
+// The MSB-first binary radix select runs on BIT-SLICED keys: the lane's 32 order-preserving words are transposed once
+// (32 x 32 bits, ~480 VALU), after which word b holds bit b of all 32 slots, the set of slots still in the race is one
+// 32-bit mask per lane, and a radix step is v_and + v_bcnt + a wave sum + one mask update (~17 instructions) whatever the
+// slot count -- against v_bfe + v_cmp + s_bcnt1 + v_and PER SLOT and step of the ballot form (~190 for 32 slots).
 template <int NV>
 __global__ __launch_bounds__(256) void sample_tau_kernel(const SelectParams p)
 {
+    static_assert(NV == 32, "one 32 x 32 bit matrix per lane");
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.B) return;
-    static_assert(NV % 4 == 0, "float4 loads");
     const float4 *d = (const float4 *)((const float *)p.cand + row * 2 * p.cap);      // dense row: NV * 64 floats
     unsigned w[NV];
-    unsigned a = ~0u, o = 0u;
-    int nz = 0;
+    unsigned a = ~0u, o = 0u, act = 0u;
 #pragma unroll
     for (int j = 0; j < NV / 4; ++j) {
         const float4 v = d[j * 64 + lane];
@@ -974,25 +1002,30 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const SelectParams p)
         for (int u = 0; u < 4; ++u) {
             const unsigned x = (f[u] != f[u]) ? 0u : orderable_f32(f[u]);             // NaN: not a candidate
             w[4 * j + u] = x;
-            if (x) { a &= x; o |= x; }
-            nz += x != 0u;                                      // per lane; summed over the wave below
+            if (x) { a &= x; o |= x; act |= 0x80000000u >> (4 * j + u); }             // slot c lives at bit 31 - c
         }
     }
-    {
-        int total;
-        (void)wave_scan_incl(nz, lane, total);
-        nz = total;
-    }
-    if (nz < p.k) return;                                       // tau stays -inf
+    int n_act = (int)wave_sum_u32((unsigned)__popc(act));
+    if (n_act < p.k) return;                                    // tau stays -inf
     a = wave_and_u32(a);
     o = wave_or_u32(o);
-    int r = p.k, n_act = nz;
-    radix_narrow_u32<NV>(w, a ^ o, r, n_act);
-    unsigned f = 0u;                                            // any word still standing is the answer (equal values all stand)
+    const unsigned var = a ^ o;                                 // the bits in which the words differ at all
+    bit_transpose32(w);                                         // w[31 - b] = bit b of every slot
+    int r = p.k;
+    unsigned kth = a & ~var;                                    // the bits every word agrees on
 #pragma unroll
-    for (int i = 0; i < NV; ++i) f |= w[i];
-    const unsigned long long has = __ballot(f != 0u);
-    const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)f, has ? __builtin_ctzll(has) : 0);
+    for (int b = 31; b >= 0; --b) {
+        if (!(var & (1u << b))) continue;                       // wave-uniform: scalar branch
+        const unsigned ones = act & w[31 - b];                  // slots in the race that have bit b set
+        const int cnt1 = (int)wave_sum_u32((unsigned)__popc(ones));
+        if (cnt1 >= r) {                                        // the r-th largest has the bit set: the zeros drop out
+            act = ones;
+            kth |= 1u << b;
+        } else {                                                // it has the bit clear: the ones drop out
+            r -= cnt1;
+            act &= ~w[31 - b];
+        }
+    }
     if (lane == 0) {
         p.tau[row] = from_orderable(kth);
         p.topk_n[row] = 0;

@@ -4,6 +4,8 @@ hand-off removed, to apportion what a candidate costs in the candidate-dense ear
     noatomic  every hit is stored at slot 0 of its segment (no LDS slot request)
     nostore   the slot is requested, nothing is stored
     nohit     the hit test is kept, hits do nothing
+    nomask    as built, but the per-row tile bitmask is not updated (no global atomicOr)
+    nocnt     as built, but neither the per-tile counts nor the tile bitmask are written
 usage: python tools/ablation/make_epilogue_variants.py   -> image-classification_amd/libmi_knn_{noatomic,nostore,nohit}.so"""
 import os
 import shutil
@@ -18,14 +20,24 @@ NEW = {
     "nostore": "atomicAdd(lcnt + rl, 1u);",
     "nohit": "asm volatile(\"\" :: \"v\"(v));",
 }
+MASK_OLD = "if (n) atomicOr(p.tmask + (long long)(q0 + tid) * p.mask_words + (st >> 5), 1u << (st & 31));"
+CNT_OLD = "p.cnt2[(long long)st * p.bpad + q0 + tid] = (unsigned short)n;           // one contiguous block per tile"
+NEW["nomask"] = None
+NEW["nocnt"] = None
 for name, new in NEW.items():
     with tempfile.TemporaryDirectory() as d:
         shutil.copytree(os.path.join(PKG, "csrc"), os.path.join(d, "pkg", "csrc"))
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
         p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
         s = open(p).read()
-        assert s.count(OLD) == 1
-        open(p, "w").write(s.replace(OLD, new))
+        assert s.count(OLD) == 1 and s.count(MASK_OLD) == 1 and s.count(CNT_OLD) == 1
+        if name == "nomask":
+            s = s.replace(MASK_OLD, "asm volatile(\"\" :: \"v\"(n));")
+        elif name == "nocnt":
+            s = s.replace(MASK_OLD, "asm volatile(\"\" :: \"v\"(n));").replace(CNT_OLD, "")
+        else:
+            s = s.replace(OLD, new)
+        open(p, "w").write(s)
         out = os.path.join(PKG, f"libmi_knn_{name}.so")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                                "-o", out, "mi_knn.hip"], cwd=os.path.join(d, "pkg", "csrc"))

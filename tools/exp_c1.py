@@ -22,3 +22,13 @@ for _ in range(10):
     ica.knn_predict(f, bank_t, lab, C, 200, 0.1, compute_dtype=dt)
 e1.record(); torch.cuda.synchronize()
 print(dt, e0.elapsed_time(e1) / 10, "ms per knn_predict")
+from image_classification_amd import _lib
+_lib.profile_enable(True)
+for _ in range(10):
+    ica.knn_predict(f, bank_t, lab, C, 200, 0.1, compute_dtype=dt)
+torch.cuda.synchronize()
+sim_ms, n, fl = _lib.profile_collect(0)
+sel_ms, n2, _ = _lib.profile_collect(1)
+_lib.profile_enable(False)
+print(f"{dt} {os.environ.get('MI_KNN_LIB', 'libmi_knn.so').split('/')[-1]}: similarity kernels {sim_ms / 10 * 1e3:.1f} us per call ({n // 10} launches, {fl / sim_ms / 1e9:.0f} TFLOP/s), "
+      f"select kernels {sel_ms / 10 * 1e3:.1f} us per call")
