@@ -12,10 +12,10 @@ LIB_PATH = os.environ.get("MI_KNN_LIB") or os.path.join(HERE, "libmi_knn.so")   
 
 MI_F32, MI_BF16 = 0, 1
 MI_MAX_K, MI_MAX_CLASSES = 1024, 65536
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = [
-    "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_profile_clock", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes", "mi_knn_topk_workspace_bytes_for_budget",
+    "mi_abi_version", "mi_last_error", "mi_profile_enable", "mi_profile_collect", "mi_profile_clock", "mi_debug_force_fallback", "mi_knn_ld", "mi_pack_rows", "mi_knn_topk_workspace_bytes", "mi_knn_topk_workspace_bytes_for_budget",
     "mi_knn_topk", "mi_knn_topk_static", "mi_knn_merge", "mi_knn_vote", "mi_queue_push", "mi_bank_scatter", "mi_moco_workspace_bytes",
     "mi_moco_fwd", "mi_moco_bwd", "mi_queue_push_stash", "mi_bank_append_normalized", "mi_queue_push_wrap", "mi_soft_knn_workspace_bytes", "mi_soft_knn", "mi_kth_largest",
 ]
@@ -45,6 +45,7 @@ def lib() -> ctypes.CDLL:
     L.mi_profile_collect.restype = i32
     L.mi_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
     L.mi_profile_clock.restype, L.mi_profile_clock.argtypes = i32, [p, i64]
+    L.mi_debug_force_fallback.restype, L.mi_debug_force_fallback.argtypes = i32, [i32]
     L.mi_pack_rows.restype = i32
     L.mi_pack_rows.argtypes = [p, i64, i32, i64, i64, i32, p, i64, p]
     L.mi_bank_append_normalized.restype = i32

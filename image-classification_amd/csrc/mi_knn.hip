@@ -218,7 +218,10 @@ __global__ __launch_bounds__(256) void append_normalized_vec_kernel(const float 
     }
 }
 
-__global__ void init_state_kernel(float *tau, int *topk_n, unsigned *big_cnt, unsigned *tmask, int mask_words, int B, int B_pad)
+// fb_*: state of the speculation fallback (null / 0 when the pass does not speculate): the failed-row counter, the safe
+// thresholds, and the compact rows' tile masks and key counts, all of which must start at zero / -inf
+__global__ void init_state_kernel(float *tau, int *topk_n, unsigned *big_cnt, unsigned *tmask, int mask_words, int B, int B_pad,
+                                  float *tau0, unsigned *fail_cnt, unsigned *fb_tmask, int fb_mask_words, int *fb_topk_n, int fb_rows)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B_pad)
@@ -227,6 +230,12 @@ __global__ void init_state_kernel(float *tau, int *topk_n, unsigned *big_cnt, un
     if (i < B_pad) {
         tau[i] = i < B ? -INFINITY : INFINITY;
         topk_n[i] = 0;
+        if (tau0) tau0[i] = -INFINITY;
+    }
+    if (fail_cnt && i == 0) *fail_cnt = 0u;
+    if (i < fb_rows) {
+        fb_topk_n[i] = 0;
+        for (int j = 0; j < fb_mask_words; ++j) fb_tmask[(long long)i * fb_mask_words + j] = 0u;
     }
 }
 
@@ -360,6 +369,12 @@ struct Plan {
     int launch_cols;    // columns of one GEMM launch (<= cap): a stage is one or more launches, then ONE refresh
     size_t off_tau, off_topkn, off_big, off_topk, off_mask, off_cnt2, off_cand, fixed, total;
     int mask_words;
+    // speculation (see spec_rank below): state of the exact fallback.  fb_rows = 0: the pass does not speculate.
+    int spec_rank;      // rank of the speculative first threshold in the sample (== k: none)
+    int fb_rows;        // compact rows one fallback round redoes (multiple of 256): fb_rows * N_pad slots fit the candidate buffer
+    int fb_rounds;      // ceil(B_pad / fb_rows): every row can be redone, whatever fails
+    int fb_ntiles, fb_mask_words;
+    size_t off_tau0, off_fail, off_fb_topk, off_fb_topkn, off_fb_mask, off_fb_cnt2, total_spec;
 };
 
 constexpr int S0_COLS = 2048;           // dense bootstrap columns
@@ -369,6 +384,27 @@ inline int big_stride(int B_pad) { return 4 * (int)ceil_div(B_pad, 4 * mi::BIG_S
 constexpr int STAGE_QUANTUM = 1024;                // filter stages are whole multiples of 4 bank tiles
 constexpr int64_t FIT_BYTES = (int64_t)128 << 20;             // bank slice of one launch: stays in the 256 MiB Infinity Cache
 constexpr int64_t CAND_BUDGET_BYTES = (int64_t)8 << 30;       // default size of the candidate buffer
+
+// Speculative first threshold.  The safe first threshold -- the k-th largest of the S sampled similarities of a row --
+// lets ~k/S of all elements through (10 % at k = 200, S = 2048) until the first stages have raised it, and those
+// candidate-dense ramp stages are what a small bank (CIFAR: all of it) and a small row shard pay most for.  The row's
+// FINAL k-th similarity sits near rank m = k S / N of the sample, far above rank k.  So the filter starts with the
+// r-th largest sample value instead, r << k chosen such that, for a strided sample of an exchangeable bank, fewer than
+// k of the N bank rows reach it with probability < 1e-9 per row: the count above the r-th order statistic of S
+// uniform draws is N x Gamma(r) / S, and P(Gamma(r) < m) <= m^r e^-m / r! / (1 - m / (r + 1)).  The threshold still
+// only rises (the bag's k-th key takes over once it is higher).  Exactness does not rest on the estimate: a row that
+// ends the pass with fewer than k keys is redone from its safe threshold (fallback rounds in knn_topk_impl) -- whatever
+// the bank looks like, the result is the exact top-k; only the time is statistical.
+int spec_rank(int64_t N, int k, int S)
+{
+    const double m = (double)k * (double)S / (double)N;
+    for (int r = 4; r < k; ++r) {
+        if ((double)r + 1.0 <= 2.0 * m) continue;                          // keep the series bound tight: m / (r + 1) < 1/2
+        const double logp = r * log(m) - m - lgamma((double)r + 1.0) - log(1.0 - m / ((double)r + 1.0));
+        if (logp < log(1e-9)) return r;
+    }
+    return k;
+}
 
 // Workspace layout.  cand_bytes < 0: the default candidate budget; otherwise what the caller gave.
 Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row_bytes = 0)
@@ -410,6 +446,31 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
     pl.off_cnt2 = take((size_t)(pl.cap / mi::TILE) * pl.B_pad * 2);
     pl.off_cand = take((size_t)pl.B_pad * pl.cap * 8);
     pl.total = off;
+    // speculation: worth it when the sample is a strict subset of the bank, the refresh is the register-resident one
+    // (k <= 256) and at least one 256-row query tile can be redone against the WHOLE bank in one stage
+    pl.spec_rank = k;
+    pl.fb_rows = pl.fb_rounds = 0;
+    pl.total_spec = pl.total;
+    const int64_t n_pad = round_up(N, mi::TILE);
+    if (N > S0_COLS && k <= mi::WSEL_MAX_K && pl.cap > 0) {
+        const int r = spec_rank(N, k, S0_COLS);
+        int64_t fb = (int64_t)pl.B_pad * pl.cap / n_pad / mi::TILE * mi::TILE;
+        if (fb > pl.B_pad) fb = pl.B_pad;
+        if (r < k && fb >= mi::TILE && ceil_div(pl.B_pad, fb) <= 16) {
+            pl.spec_rank = r;
+            pl.fb_rows = (int)fb;
+            pl.fb_rounds = (int)ceil_div(pl.B_pad, fb);
+            pl.fb_ntiles = (int)(n_pad / mi::TILE);
+            pl.fb_mask_words = (int)ceil_div(pl.fb_ntiles, 32);
+            pl.off_tau0 = take((size_t)pl.B_pad * 4);
+            pl.off_fail = take(256 + (size_t)pl.B_pad * 4);                 // counter (own line) + failed rows
+            pl.off_fb_topk = take((size_t)pl.fb_rows * k * 8);
+            pl.off_fb_topkn = take((size_t)pl.fb_rows * 4);
+            pl.off_fb_mask = take((size_t)pl.fb_rows * pl.fb_mask_words * 4);
+            pl.off_fb_cnt2 = take((size_t)pl.fb_ntiles * pl.fb_rows * 2);
+            pl.total_spec = off;
+        }
+    }
     return pl;
 }
 
@@ -435,12 +496,15 @@ int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t left)      // left
     return n;
 }
 
+// mi_debug_force_fallback: rows with row % modulus == 0 are reported as failed speculations (tests of the fallback path)
+std::atomic<int> g_force_mod{0};
+
 // mi_profile_clock: when a stamp buffer is registered, filter launches run the STAMP instantiation of the kernel
 std::mutex g_stamp_mu;
 unsigned long long *g_stamp_buf = nullptr;
 int g_stamp_cap = 0;
 
-template <int DT, int MODE>
+template <int DT, int MODE, bool FB = false>
 hipError_t launch_sim(const mi::SimParams &p_in, hipStream_t s)
 {
     // 32 consecutive same-XCD workgroups form one patch of (1 << qsh) query tiles x (32 >> qsh) bank
@@ -455,7 +519,10 @@ hipError_t launch_sim(const mi::SimParams &p_in, hipStream_t s)
     p.pn = (int)ceil_div(p.ntiles, 32 >> qsh);
     const int patches = p.pq * p.pn;
     const int grid = (int)ceil_div(patches, 8) * 256;
-    if constexpr (MODE == mi::MODE_FILTER) {
+    if constexpr (FB) {
+        hipLaunchKernelGGL((mi::sim_kernel<DT, MODE, false, true>), dim3(grid), dim3(mi::SIM_THREADS), 0, s, p);
+        return hipGetLastError();
+    } else if constexpr (MODE == mi::MODE_FILTER) {
         std::lock_guard<std::mutex> lk(g_stamp_mu);
         if (g_stamp_buf) {
             p.stamps = g_stamp_buf;
@@ -516,6 +583,13 @@ int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *to
     if (total_ms) *total_ms = ms;
     if (launches) *launches = n;
     if (total_work) *total_work = work;
+    return MI_OK;
+}
+
+int mi_debug_force_fallback(int modulus)
+{
+    if (modulus < 0) return fail(MI_ERR_ARG, "mi_debug_force_fallback: modulus must be >= 0");
+    g_force_mod.store(modulus);
     return MI_OK;
 }
 
@@ -595,7 +669,7 @@ size_t mi_knn_topk_workspace_bytes_for_budget(int64_t B, int64_t N, int k, size_
     const int64_t budget = candidate_bytes > ((size_t)1 << 46) ? ((int64_t)1 << 46) : (int64_t)candidate_bytes;
     Plan pl = make_plan(B, N, k, budget);
     if (pl.cap == 0) pl = make_plan(B, N, k, -1);             // below the minimum: the default (it covers the minimum)
-    return pl.total + 2048 + 4 * (size_t)round_up(B, mi::TILE);        // + the alignment slack make_plan reserves when it sizes from a byte count
+    return pl.total_spec + 2048 + 4 * (size_t)round_up(B, mi::TILE);   // + the alignment slack make_plan reserves when it sizes from a byte count
 }
 
 }  // extern "C"
@@ -618,7 +692,17 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
     if (((uintptr_t)q | (uintptr_t)bank | (uintptr_t)workspace) & 15) return fail(MI_ERR_ARG, "mi_knn_topk: q, bank and workspace must be 16-byte aligned");
     // the stage size follows the workspace the caller actually gave (more memory = fewer, larger stages)
     const size_t fixed = make_plan(B, N, k, -1).fixed;
-    const Plan pl = make_plan(B, N, k, workspace_bytes > fixed ? (int64_t)(workspace_bytes - fixed) : 0, ld * elt_bytes(dtype));
+    Plan pl = make_plan(B, N, k, workspace_bytes > fixed ? (int64_t)(workspace_bytes - fixed) : 0, ld * elt_bytes(dtype));
+    // speculation is opportunistic: used when the state of its fallback fits the workspace as well (the result never
+    // depends on it); a workspace sized by mi_knn_topk_workspace_bytes* always has the room
+    bool spec = pl.cap > 0 && pl.fb_rows > 0 && pl.total_spec <= workspace_bytes;
+    if (!spec && pl.cap > 0 && pl.fb_rows > 0) {
+        const size_t extra = pl.total_spec - pl.total + 4096;
+        if (workspace_bytes > fixed + extra) {
+            const Plan p2 = make_plan(B, N, k, (int64_t)(workspace_bytes - fixed - extra), ld * elt_bytes(dtype));
+            if (p2.cap > 0 && p2.fb_rows > 0 && p2.total_spec <= workspace_bytes) { pl = p2; spec = true; }
+        }
+    }
     if (pl.cap == 0 || workspace_bytes < pl.total)
         return fail(MI_ERR_WORKSPACE, "mi_knn_topk: workspace %zu is below the minimum %zu (recommended: mi_knn_topk_workspace_bytes)",
                     workspace_bytes, fixed + 2048 + 4 * (size_t)pl.B_pad + (size_t)S0_COLS * ((size_t)pl.B_pad * 8 + pl.B_pad / 128 + 1));
@@ -634,7 +718,13 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
 
     unsigned *big_cnt = (unsigned *)(ws + pl.off_big);
     int *big_rows = (int *)(ws + pl.off_big + BIG_CNT_BYTES);
-    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, topk_n, big_cnt, tmask, pl.mask_words, (int)B, pl.B_pad);
+    float *tau0 = spec ? (float *)(ws + pl.off_tau0) : nullptr;
+    unsigned *fail_cnt = spec ? (unsigned *)(ws + pl.off_fail) : nullptr;
+    int *fail_rows = spec ? (int *)(ws + pl.off_fail + 256) : nullptr;
+    unsigned *fb_mask = spec ? (unsigned *)(ws + pl.off_fb_mask) : nullptr;
+    int *fb_topkn = spec ? (int *)(ws + pl.off_fb_topkn) : nullptr;
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)ceil_div(pl.B_pad, 256)), dim3(256), 0, s, tau, topk_n, big_cnt, tmask, pl.mask_words, (int)B, pl.B_pad,
+                       tau0, fail_cnt, fb_mask, spec ? pl.fb_mask_words : 0, fb_topkn, spec ? pl.fb_rows : 0);
     HIP_CHECK(hipGetLastError());
 
     mi::SimParams sp{};
@@ -667,6 +757,11 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
     sel.tau = tau;
     sel.k = k;
     sel.idx_base = idx_base;
+    sel.tau0 = tau0;
+    sel.spec_rank = spec ? pl.spec_rank : k;
+    sel.fail_cnt = fail_cnt;
+    sel.fail_rows = fail_rows;
+    sel.force_mod = spec ? g_force_mod.load() : 0;
 
     // stage 0: dense bootstrap.  A bank no larger than the bootstrap is finished by it.  Otherwise the bootstrap
     // runs over a STRIDED SAMPLE of the bank (every floor(N / s0)-th row: whatever order the bank is in -- an
@@ -736,6 +831,61 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
                 HIP_CHECK(hipGetLastError());
             }
         }
+    }
+    if (!spec) return MI_OK;
+
+    // Fallback of the speculative first threshold (spec_rank above).  The final refresh listed the rows that ended with
+    // fewer than k keys; each round redoes up to fb_rows of them EXACTLY: one filter stage over the whole bank from the
+    // row's safe sample threshold (the candidate buffer holds fb_rows x N slots: nothing can overflow), then one
+    // refresh that writes the row's final top-k.  Nothing has failed in the normal case, and both launches of a round
+    // are empty: every workgroup reads the counter and exits.  No host synchronisation either way.
+    const int64_t n_pad = round_up(N, mi::TILE);
+    mi::SimParams fp = sp;
+    fp.B = pl.fb_rows;
+    fp.qtiles = pl.fb_rows / mi::TILE;
+    fp.cnt2 = (unsigned short *)(ws + pl.off_fb_cnt2);
+    fp.tmask = fb_mask;
+    fp.mask_words = pl.fb_mask_words;
+    fp.bpad = pl.fb_rows;
+    fp.cap = (int)n_pad;
+    fp.fb_rows = fail_rows;
+    fp.fb_cnt = fail_cnt;
+    fp.fb_tau0 = tau0;
+    mi::SelectParams fs = sel;
+    fs.cnt2 = fp.cnt2;
+    fs.tmask = fb_mask;
+    fs.mask_words = pl.fb_mask_words;
+    fs.bpad = pl.fb_rows;
+    fs.cap = (int)n_pad;
+    fs.ntiles = pl.fb_ntiles;
+    fs.B = pl.fb_rows;
+    fs.topk = (unsigned long long *)(ws + pl.off_fb_topk);
+    fs.topk_n = fb_topkn;
+    fs.out_val = out_val;
+    fs.out_idx = (long long *)out_idx;
+    fs.tau0 = nullptr;
+    fs.fail_cnt = nullptr;              // a redone row is final
+    fs.force_mod = 0;
+    fs.fb_rows = fail_rows;
+    fs.fb_cnt = fail_cnt;
+    for (int round = 0; round < pl.fb_rounds; ++round) {
+        fp.fb_base = fs.fb_base = round * pl.fb_rows;
+        // ONE launch over the whole bank (no cache-fit slicing for a path that is empty but for pathological banks:
+        // an empty launch costs ~2 us, and a sliced round would be dozens of them)
+        fp.col0 = 0;
+        fp.ncols = (int)N;
+        fp.ntiles = pl.fb_ntiles;
+        fp.nt_base = 0;
+        if (dtype == MI_BF16) HIP_CHECK((launch_sim<mi::DT_BF16, mi::MODE_FILTER, true>(fp, s)));
+        else HIP_CHECK((launch_sim<mi::DT_F32, mi::MODE_FILTER, true>(fp, s)));
+        const dim3 fgrid((unsigned)ceil_div(pl.fb_rows, 4));
+        switch ((k + 63) / 64) {
+        case 1: hipLaunchKernelGGL((mi::bag_refresh_kernel<1>), fgrid, dim3(256), 0, s, fs); break;
+        case 2: hipLaunchKernelGGL((mi::bag_refresh_kernel<2>), fgrid, dim3(256), 0, s, fs); break;
+        case 3: hipLaunchKernelGGL((mi::bag_refresh_kernel<3>), fgrid, dim3(256), 0, s, fs); break;
+        default: hipLaunchKernelGGL((mi::bag_refresh_kernel<4>), fgrid, dim3(256), 0, s, fs); break;
+        }
+        HIP_CHECK(hipGetLastError());
     }
     return MI_OK;
 }

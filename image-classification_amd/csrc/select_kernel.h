@@ -86,6 +86,19 @@ struct SelectParams {
                                 // merge_kernel zeroes the other set
     int big_stride;             // >= rows one sub-list can receive
     int parity;
+    // speculative first threshold (mi_knn.hip, "speculation"): sample_tau_kernel writes the SAFE threshold (k-th largest
+    // of the sample) to tau0 and the speculative one (spec_rank-th largest, spec_rank < k) to tau; a row that ends the
+    // pass with fewer than k keys although its sample held k real values FAILED and is appended to fail_rows.
+    float *tau0;                // [B_pad] or nullptr (no speculation)
+    int spec_rank;
+    unsigned *fail_cnt;         // one counter, zeroed at the start of the pass
+    int *fail_rows;             // [B_pad]
+    int force_mod;              // debug (mi_debug_force_fallback): rows with row % force_mod == 0 are reported failed
+    // fallback launch: row = COMPACT row c of the failed-row list; rows c >= *fb_cnt - fb_base do nothing, outputs go to
+    // query row fb_rows[fb_base + c]
+    const int *fb_rows;
+    const unsigned *fb_cnt;
+    int fb_base;
 };
 
 // LDS of one select workgroup.
@@ -1006,28 +1019,36 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const SelectParams p)
         }
     }
     int n_act = (int)wave_sum_u32((unsigned)__popc(act));
-    if (n_act < p.k) return;                                    // tau stays -inf
+    if (n_act < p.k) return;                                    // tau (and tau0) stay -inf: the row is never speculated on
     a = wave_and_u32(a);
     o = wave_or_u32(o);
     const unsigned var = a ^ o;                                 // the bits in which the words differ at all
     bit_transpose32(w);                                         // w[31 - b] = bit b of every slot
-    int r = p.k;
-    unsigned kth = a & ~var;                                    // the bits every word agrees on
+    // rank-th largest word (duplicates count) among the slots in `act0`
+    auto select = [&](int rank) {
+        unsigned in = act;
+        int r = rank;
+        unsigned kth = a & ~var;                                // the bits every word agrees on
 #pragma unroll
-    for (int b = 31; b >= 0; --b) {
-        if (!(var & (1u << b))) continue;                       // wave-uniform: scalar branch
-        const unsigned ones = act & w[31 - b];                  // slots in the race that have bit b set
-        const int cnt1 = (int)wave_sum_u32((unsigned)__popc(ones));
-        if (cnt1 >= r) {                                        // the r-th largest has the bit set: the zeros drop out
-            act = ones;
-            kth |= 1u << b;
-        } else {                                                // it has the bit clear: the ones drop out
-            r -= cnt1;
-            act &= ~w[31 - b];
+        for (int b = 31; b >= 0; --b) {
+            if (!(var & (1u << b))) continue;                   // wave-uniform: scalar branch
+            const unsigned ones = in & w[31 - b];               // slots in the race that have bit b set
+            const int cnt1 = (int)wave_sum_u32((unsigned)__popc(ones));
+            if (cnt1 >= r) {                                    // the r-th largest has the bit set: the zeros drop out
+                in = ones;
+                kth |= 1u << b;
+            } else {                                            // it has the bit clear: the ones drop out
+                r -= cnt1;
+                in &= ~w[31 - b];
+            }
         }
-    }
+        return kth;
+    };
+    const unsigned safe = select(p.k);
+    const unsigned spec = (p.tau0 && p.spec_rank < p.k) ? select(p.spec_rank) : safe;
     if (lane == 0) {
-        p.tau[row] = from_orderable(kth);
+        p.tau[row] = from_orderable(spec);                      // what the filter stages start with
+        if (p.tau0) p.tau0[row] = from_orderable(safe);         // what a failed row is redone with
         p.topk_n[row] = 0;
     }
 }
@@ -1041,6 +1062,7 @@ __global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wv;
     if (row >= p.B) return;
+    if (p.fb_rows && row >= (long long)*p.fb_cnt - p.fb_base) return;      // fallback launch: compact rows in use only
     BagSmem &sm = smem[wv];
     const bool finalize = p.out_val != nullptr;
     const int k = p.k;
@@ -1159,12 +1181,22 @@ __global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams 
                 if ((j * 64 + lane) < n_cur) p.topk[row * k + j * 64 + lane] = key[j];
             if (lane == 0) {
                 p.topk_n[row] = n_cur;
-                if (kth_last) p.tau[row] = key_value(kth_last);             // tau only ever rises
+                // tau only ever rises; under speculation it starts ABOVE the k-th key of the first stages
+                if (kth_last && key_value(kth_last) > p.tau[row]) p.tau[row] = key_value(kth_last);
             }
         }
     }
     if (finalize) {
         if (!have_bag) load_bag();
+        // speculation check: every key the filter let through is >= the speculative threshold, so the k-th of k such keys
+        // bounds everything that was filtered out -- the result is exact.  With fewer than k keys it is not known to be:
+        // the row is redone with its safe threshold (rows whose sample held fewer than k real values were never
+        // speculated on: tau0 = -inf).
+        if (p.fail_cnt && lane == 0) {
+            const bool failed = n_cur < k && p.tau0[row] > -INFINITY;
+            if (failed || (p.force_mod > 0 && row % p.force_mod == 0)) p.fail_rows[atomicAdd(p.fail_cnt, 1u)] = (int)row;
+        }
+        const long long orow = p.fb_rows ? (long long)p.fb_rows[p.fb_base + row] : row;
         // the one sort of the row: the bag's keys through the register sorting network (empty slots, 0, go last)
         unsigned long long k4[4];
 #pragma unroll
@@ -1175,8 +1207,8 @@ __global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams 
             const int i = 4 * lane + j;                                     // sorted position
             if (i < k) {
                 const bool ok = i < n_cur;
-                p.out_val[row * k + i] = ok ? key_value(k4[j]) : -INFINITY;
-                p.out_idx[row * k + i] = ok ? p.idx_base + (long long)key_row(k4[j]) : -1ll;
+                p.out_val[orow * k + i] = ok ? key_value(k4[j]) : -INFINITY;
+                p.out_idx[orow * k + i] = ok ? p.idx_base + (long long)key_row(k4[j]) : -1ll;
             }
         }
     }

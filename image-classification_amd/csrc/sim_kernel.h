@@ -72,6 +72,13 @@ struct SimParams {
     float2 *lse_part;         // [ntiles, lse_ld] (max, sumexp) of every row over one tile; lse_ld = padded rows
     int lse_ld;
     unsigned *zero_word;      // MODE_LSE: a word the NEXT kernel on the stream expects to be 0 (its arrival counter)
+    // FB instantiation only (the exact fallback of a speculative first threshold, mi_knn.hip): the launch's query rows
+    // are the COMPACT rows c = 0 .. n - 1 of the failed-row list, n = *fb_cnt - fb_base; compact row c is query row
+    // fb_rows[fb_base + c] and filters with that row's SAFE sample threshold fb_tau0[...]; workgroups beyond n exit at once
+    const int *fb_rows;
+    const unsigned *fb_cnt;
+    int fb_base;
+    const float *fb_tau0;
     // STAMP instantiation only (diagnostic, mi_profile_clock): per workgroup (shader cycles, 100 MHz ticks) of its lifetime
     unsigned long long *stamps;
     int stamp_cap;            // entries (pairs) in `stamps`; workgroup b writes pair b % stamp_cap
@@ -104,9 +111,15 @@ __device__ __forceinline__ float row16_sum(float v)
 // L2 prefetch schedule (measured): touch the lines of K-step t + PF_DIST after MFMA group PF_POS of step t
 constexpr int PF_DIST = 2, PF_POS = 4;
 
-template <int DT, int MODE, bool STAMP = false>
+template <int DT, int MODE, bool STAMP = false, bool FB = false>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
 {
+    static_assert(!FB || MODE == MODE_FILTER, "the fallback instantiation is a filter launch");
+    int fb_n = 0;                                    // FB: compact rows in use
+    if constexpr (FB) {
+        fb_n = (int)*p.fb_cnt - p.fb_base;
+        if (fb_n <= 0) return;                       // nothing failed (the normal case): the launch is empty
+    }
     __shared__ __attribute__((aligned(16))) char smem[SIM_LDS_BYTES + SIM_EXTRA_LDS];
     // Diagnostic build of the same kernel (STAMP): the in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz.
     // The stamps go to a buffer of their own; no output depends on them.  The production instantiation has none.
@@ -123,6 +136,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
     const int qt = ((patch / p.pn) << p.qsh) + (inner & ((1 << p.qsh) - 1));
     const int nt = (patch % p.pn) * (32 >> p.qsh) + (inner >> p.qsh);
     if (qt >= p.qtiles || nt >= p.ntiles) return;
+    if constexpr (FB) {
+        if (qt * TILE >= fb_n) return;               // no failed row in this query tile
+    }
     const int q0 = qt * TILE;
     const int n0 = p.col0 + nt * TILE;
     const int col_end = p.col0 + p.ncols;
@@ -141,6 +157,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         const int r = (w * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         int qa = q0 + r; qa = qa < p.B ? qa : p.B - 1;             // clamp: padding rows re-read a valid row
+        if constexpr (FB) qa = p.fb_rows[p.fb_base + (qa < fb_n ? qa : 0)];      // compact row -> query row
         int xb = n0 + r;
         if constexpr (MODE == MODE_DENSE) {                          // padding columns re-read the last sampled row
             xb = xb < col_end ? xb : col_end - 1;
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         idx = idx < la + lb ? idx : la + lb - 1;
         if (idx < la) {
             int r = q0 + la * (inner >> p.qsh) + idx; r = r < p.B ? r : p.B - 1;
+            if constexpr (FB) r = p.fb_rows[p.fb_base + (r < fb_n ? r : 0)];
             pf_src = p.q + (long long)r * p.ldq_bytes;
         } else {
             int r = n0 + lb * (inner & ((1 << p.qsh) - 1)) + (idx - la);
@@ -228,7 +246,10 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
         // thresholds of this tile's 256 query rows -> spare LDS (read back in the epilogue)
         // (the K loop's barriers publish them long before the epilogue reads them)
         if (tid < TILE) {
-            ((float *)(smem + SIM_LDS_BYTES))[tid] = p.tau[q0 + tid];
+            float t;
+            if constexpr (FB) t = (q0 + tid) < fb_n ? p.fb_tau0[p.fb_rows[p.fb_base + q0 + tid]] : INFINITY;
+            else t = p.tau[q0 + tid];
+            ((float *)(smem + SIM_LDS_BYTES))[tid] = t;
             ((unsigned *)(smem + SIM_LDS_BYTES + 1024))[tid] = 0u;
         }
     }

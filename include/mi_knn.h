@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 7
+#define MI_ABI_VERSION 8
 
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_HIP = -2, MI_ERR_WORKSPACE = -3, MI_ERR_UNSUPPORTED = -4 };
 enum { MI_F32 = 0, MI_BF16 = 1 };            /* compute dtype of the similarity GEMM            */
@@ -59,6 +59,12 @@ int mi_profile_collect(int kind, double *total_ms, int64_t *launches, double *to
  * its lifetime to pair b % entries.  clock = cycles / ticks x 100 MHz (median over workgroups).  NULL switches it
  * off.  Never on in a timed run: it is a separate build of the kernel.  Process-wide debug state behind a mutex. */
 int mi_profile_clock(void *stamps, int64_t entries);
+
+/* Debug / test switch (no reference counterpart), process-wide like mi_profile_*: mi_knn_topk starts its filter with a
+ * SPECULATIVE first threshold per query row and redoes, exactly, any row the speculation failed for.  With
+ * modulus > 0 every query row whose index is a multiple of it is treated as failed, so that the fallback runs; the results
+ * must not change.  0 switches it off. */
+int mi_debug_force_fallback(int modulus);
 
 /* Leading dimension (in ELEMENTS of `dtype`) the similarity kernels require for a D-wide row:
  * D rounded up so that a row is a whole number of 128-byte K-steps (32 f32 / 64 bf16). */

@@ -147,6 +147,51 @@ def test_adversarial_ascending_similarity(ica):
     assert np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
 
 
+# ----------------------------------------------------------------------------- speculative first threshold + exact fallback
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,N,D,k,mod", [(700, 60000, 64, 200, 3), (300, 9000, 128, 50, 1), (1000, 200000, 32, 200, 7)])
+def test_forced_fallback_redoes_rows_exactly(ica, dtype, B, N, D, k, mod):
+    """mi_knn_topk filters from a speculative first threshold and redoes the rows it failed for.  With
+    mi_debug_force_fallback every mod-th row is REPORTED failed, so the fallback path (one whole-bank stage from the safe
+    threshold, final refresh into the original rows) runs for real: the result must equal the undisturbed run bit for
+    bit, and (fp32) the chain oracle."""
+    f, x, lab = _rand_case(B, N, D, 10, B + N + k)
+    bank = ica.BankIndex.from_rows(dev(x), dtype)
+    v0, i0 = ica.knn_topk(dev(f), bank, k)
+    L = ica._lib.lib()
+    ica._lib.check(L.mi_debug_force_fallback(mod), "mi_debug_force_fallback")
+    try:
+        v1, i1 = ica.knn_topk(dev(f), bank, k)
+        torch.cuda.synchronize()
+    finally:
+        ica._lib.check(L.mi_debug_force_fallback(0), "mi_debug_force_fallback")
+    assert torch.equal(v0, v1) and torch.equal(i0, i1)
+    if dtype == "fp32":
+        v_ref, i_ref = chain.topk_rows(chain.sim_chain_f32(f, x), k)
+        assert np.array_equal(v1.cpu().numpy(), v_ref) and np.array_equal(i1.cpu().numpy(), i_ref)
+
+
+@pytest.mark.parametrize("n_bad", [5, 300])
+def test_speculation_that_fails_falls_back_exactly(ica, n_bad):
+    """A bank the strided sample misjudges: exactly the sampled rows (every floor(N / 2048)-th) resemble the first n_bad
+    queries, no other row does.  The sample then promises ~N / 2048 times more near neighbours than the bank holds, the
+    speculative threshold lets fewer than k rows through for those queries, and they must come out exact all the same
+    (fp32: bit-equal to the chain oracle); the other queries see an ordinary random bank."""
+    rs = np.random.RandomState(11)
+    B, N, D, k = 400, 50000, 64, 200
+    stride = N // 2048
+    u = ko.l2_normalize(rs.randn(1, D))[0]
+    x = ko.l2_normalize(rs.randn(N, D))
+    x[np.arange(2048) * stride] = ko.l2_normalize(u[None, :] + 0.05 * rs.randn(2048, D))
+    f = ko.l2_normalize(rs.randn(B, D))
+    f[:n_bad] = ko.l2_normalize(u[None, :] + 0.05 * rs.randn(n_bad, D))
+    x, f = x.astype(np.float32), f.astype(np.float32)
+    v_ref, i_ref = chain.topk_rows(chain.sim_chain_f32(f, x), k)
+    assert np.all(np.isin(i_ref[:n_bad], np.arange(2048) * stride))          # their neighbours ARE the sampled rows
+    v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), "fp32"), k)
+    assert np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+
+
 def test_all_ties_pick_lowest_indices(ica):
     D, N, B, k = 32, 7000, 5, 200
     x = np.tile(np.full((1, D), 0.125, np.float32), (N, 1))
