@@ -38,6 +38,12 @@ for name, new in NEW.items():
         else:
             s = s.replace(OLD, new)
         open(p, "w").write(s)
+        # no speculation: a variant that drops candidates would make every row look like a failed speculation
+        h = os.path.join(d, "pkg", "csrc", "mi_knn.hip")
+        hs = open(h).read()
+        nospec = "    if (N > S0_COLS && k <= mi::WSEL_MAX_K && pl.cap > 0) {"
+        assert hs.count(nospec) == 1
+        open(h, "w").write(hs.replace(nospec, nospec.replace("if (N >", "if (false && N >")))
         out = os.path.join(PKG, f"libmi_knn_{name}.so")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                                "-o", out, "mi_knn.hip"], cwd=os.path.join(d, "pkg", "csrc"))
