@@ -1214,6 +1214,105 @@ __global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams 
     }
 }
 
+// Cross-shard merge for k <= 256 and at most 2048 candidates per query (8 shards x k = 200: 1600): ONE wave per query row,
+// the row's G x kc candidates in registers (32 key slots per lane), the k-th largest key by the bit-sliced radix select
+// of sample_tau_kernel -- on the value word, and on the row word among equal values -- then the k survivors compacted
+// through 2 KiB of wave-private LDS, sorted once by the register network and written out.  Replaces the
+// workgroup-per-row LDS radix select + bitonic sort (select_kernel<SRC_GATHER>: 41 us / 1.07 TB/s per 2048 rows at G = 8),
+// which stays for larger k or more candidates.  Keys are distinct (global rows are); ties in value go to the lower row.
+constexpr int MERGE_WAVE_SLOTS = 32;
+__global__ __launch_bounds__(256) void merge_wave_kernel(const SelectParams p)
+{
+    __shared__ unsigned long long bag_all[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wv;
+    if (row >= p.B) return;
+    unsigned long long *bag = bag_all[wv];
+    const int k = p.k, total = p.G * p.kc;
+    unsigned hi[MERGE_WAVE_SLOTS], lo[MERGE_WAVE_SLOTS], w[MERGE_WAVE_SLOTS];
+    unsigned a = ~0u, o = 0u, act = 0u;
+#pragma unroll
+    for (int s2 = 0; s2 < MERGE_WAVE_SLOTS; ++s2) {
+        const int j = s2 * 64 + lane;
+        unsigned long long key = 0ull;
+        if (j < total) {
+            const int g = j / p.kc, c = j - g * p.kc;
+            const long long e = ((long long)g * p.B + row) * p.kc + c;
+            const long long gi = p.g_idx[e];
+            if (gi >= 0) key = make_key(p.g_val[e], (unsigned)gi);          // padding (-1) and NaN: not a candidate
+        }
+        hi[s2] = (unsigned)(key >> 32);
+        lo[s2] = (unsigned)key;
+        w[s2] = hi[s2];
+        if (key) { a &= hi[s2]; o |= hi[s2]; act |= 0x80000000u >> s2; }      // slot c lives at bit 31 - c
+    }
+    const int nz = (int)wave_sum_u32((unsigned)__popc(act));
+    const int keep = nz < k ? nz : k;
+    unsigned long long kth = 1ull;                                          // fewer than k real keys: keep every one
+    if (nz >= k) {
+        a = wave_and_u32(a);
+        o = wave_or_u32(o);
+        // rank-th largest word among the slots in `in` (MSB first, over the bits in `var`); leaves the slots that hold it
+        auto select = [&](unsigned var, unsigned common, unsigned &in, int &r) {
+            unsigned res = common & ~var;
+#pragma unroll
+            for (int b = 31; b >= 0; --b) {
+                if (!(var & (1u << b))) continue;
+                const unsigned ones = in & w[31 - b];
+                const int cnt1 = (int)wave_sum_u32((unsigned)__popc(ones));
+                if (cnt1 >= r) { in = ones; res |= 1u << b; }
+                else { r -= cnt1; in &= ~w[31 - b]; }
+            }
+            return res;
+        };
+        bit_transpose32(w);
+        unsigned in = act;
+        int r = k;
+        const unsigned kth_hi = select(a ^ o, a, in, r);                     // by value ...
+        // ... then, among the slots that hold exactly that value, by the row word (0xFFFFFFFF - row: lower row = larger)
+        unsigned al = ~0u, ol = 0u;
+#pragma unroll
+        for (int s2 = 0; s2 < MERGE_WAVE_SLOTS; ++s2) {
+            w[s2] = lo[s2];
+            if (in & (0x80000000u >> s2)) { al &= lo[s2]; ol |= lo[s2]; }
+        }
+        al = wave_and_u32(al);
+        ol = wave_or_u32(ol);
+        unsigned kth_lo = al;                                               // one slot left: its row word
+        if (al != ol) {                                                     // several rows share the k-th value
+            bit_transpose32(w);
+            kth_lo = select(al ^ ol, al, in, r);
+        }
+        kth = ((unsigned long long)kth_hi << 32) | kth_lo;
+    }
+    // compact the survivors (exactly `keep`: keys are distinct), sort them, write them out
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < MERGE_WAVE_SLOTS; ++s2) {
+        const unsigned long long key = ((unsigned long long)hi[s2] << 32) | lo[s2];
+        const bool take = key >= kth && key != 0ull;
+        const unsigned long long bal = __ballot(take);
+        const int at = base + __popcll(bal & ltmask);
+        if (take && at < 256) bag[at] = key;
+        base += __popcll(bal);
+    }
+    wave_step();
+    unsigned long long k4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k4[j] = (j * 64 + lane) < keep ? bag[j * 64 + lane] : 0ull;
+    wave_sort256<unsigned long long, true>(k4, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * lane + j;
+        if (i < k) {
+            const bool ok = i < keep;
+            p.out_val[row * k + i] = ok ? key_value(k4[j]) : -INFINITY;
+            p.out_idx[row * k + i] = ok ? (long long)key_row(k4[j]) : -1ll;
+        }
+    }
+}
+
 // k-th largest value of a 1-D float bank (track_semi/chmatch.py:252,294: `bank.topk(k)[0][-1]`, k up to 0.8 n):
 // MSB-first radix select over the order-preserving key of every element, 4 passes of 8 bits, one workgroup
 // (the bank is 50 000 floats: 200 KB, L2 resident; the kernel is latency-, not bandwidth-bound).  Selection

@@ -65,7 +65,7 @@ def main():
     cv = torch.rand((G, Bm, k), generator=g, device=dev).sort(dim=2, descending=True).values
     ci = torch.randint(0, Nl, (G, Bm, k), generator=g, device=dev)
     t = timed(lambda: ica.knn_merge(cv, ci, k))
-    line("select_kernel<GATHER> (shard merge)", G * Bm * k * 12 + Bm * k * 12, t, f"G={G} B={Bm} k={k}")
+    line("merge_wave_kernel (shard merge)", G * Bm * k * 12 + Bm * k * 12, t, f"G={G} B={Bm} k={k}")
     # MoCo queue: truncating ring push (memory_bank.py:65-72) and StorageBank scatter (:32)
     mb = ica.MemoryBank()
     mb.register("negative", dim=128, k=65536)
