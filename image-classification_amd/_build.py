@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi_knn.so")
 SOURCES = ["mi_knn.hip"]
-HEADERS = ["sim_kernel.h", "select_kernel.h", "vote_kernel.h", "moco_kernel.h",
+HEADERS = ["sim_kernel.h", "sim_walk_kernel.h", "select_kernel.h", "vote_kernel.h", "moco_kernel.h",
            os.path.join("..", "..", "include", "mi_knn.h")]
 
 

@@ -17,6 +17,7 @@
 #include "moco_kernel.h"
 #include "select_kernel.h"
 #include "sim_kernel.h"
+#include "sim_walk_kernel.h"
 #include "vote_kernel.h"
 
 namespace {
@@ -535,6 +536,45 @@ hipError_t launch_sim(const mi::SimParams &p_in, hipStream_t s)
     return hipGetLastError();
 }
 
+// Filter launch for short rows (<= 2 K-steps: D <= 128 bf16, D <= 64 f32): sim_walk_kernel.h.  One workgroup per CU
+// (130 KiB of LDS), so the bank tiles of the launch are cut into runs such that qtiles x runs fills whole rounds of CUs.
+int compute_units()
+{
+    static std::atomic<int> cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+hipError_t launch_walk(int dtype, const mi::SimParams &p_in, hipStream_t s)
+{
+    mi::SimParams p = p_in;
+    const int cus = compute_units();
+    // tiles per run: the run length that minimises rounds x (run + ~1.5 tiles of per-workgroup set-up)
+    double best = 1e30;
+    int best_tp = p.ntiles;
+    for (int tp = p.ntiles; tp >= 1; --tp) {
+        const int64_t nwg = (int64_t)p.qtiles * ceil_div(p.ntiles, tp);
+        const double cost = (double)ceil_div(nwg, cus) * (tp + 1.5);
+        if (cost < best) { best = cost; best_tp = tp; }
+    }
+    p.walk_tps = best_tp;
+    p.walk_nsplit = (int)ceil_div(p.ntiles, best_tp);
+    const int64_t nwg = (int64_t)p.qtiles * p.walk_nsplit;
+    const dim3 grid((unsigned)(ceil_div(nwg, 8) * 8));
+    // the query tile (ksteps x 32 KiB) stays resident in LDS.  (The variant that streams both operands, for rows of
+    // 257 .. 512 bytes, measured 3 % SLOWER than sim_kernel.h at f32 D = 128 and is not instantiated.)
+    if (dtype == MI_BF16) hipLaunchKernelGGL((mi::sim_walk_kernel<mi::DT_BF16, true>), grid, dim3(mi::SIM_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((mi::sim_walk_kernel<mi::DT_F32, true>), grid, dim3(mi::SIM_THREADS), 0, s, p);
+    return hipGetLastError();
+}
+constexpr int WALK_MAX_KSTEPS = 2;      // rows of at most 256 bytes: bf16 D <= 128, f32 D <= 64
+
 template <int MODE>
 hipError_t launch_sim_dt(int dtype, const mi::SimParams &p, hipStream_t s)
 {
@@ -805,7 +845,8 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
             sp.ntiles = (int)ceil_div(lc, mi::TILE);
             sp.nt_base = (int)(off / mi::TILE);
             ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)lc * (double)D, s);
-            HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
+            if (sp.ksteps <= WALK_MAX_KSTEPS) HIP_CHECK(launch_walk(dtype, sp, s));
+            else HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
         }
         col += ncols;
         if (col >= N) { sel.out_val = out_val; sel.out_idx = (long long *)out_idx; }

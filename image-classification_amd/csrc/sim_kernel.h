@@ -72,6 +72,8 @@ struct SimParams {
     float2 *lse_part;         // [ntiles, lse_ld] (max, sumexp) of every row over one tile; lse_ld = padded rows
     int lse_ld;
     unsigned *zero_word;      // MODE_LSE: a word the NEXT kernel on the stream expects to be 0 (its arrival counter)
+    // sim_walk_kernel.h only: workgroup v of qtiles * walk_nsplit walks bank tiles [split * walk_tps, (split + 1) * walk_tps)
+    int walk_nsplit, walk_tps;
     // FB instantiation only (the exact fallback of a speculative first threshold, mi_knn.hip): the launch's query rows
     // are the COMPACT rows c = 0 .. n - 1 of the failed-row list, n = *fb_cnt - fb_base; compact row c is query row
     // fb_rows[fb_base + c] and filters with that row's SAFE sample threshold fb_tau0[...]; workgroups beyond n exit at once
@@ -425,12 +427,27 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_kernel(const SimParams p)
                 if (__any(m >= t)) {
                     const int rl = wm * 128 + lq * 4 + i * 16 + r;        // row within the tile
                     if (q0 + rl < p.B) {
-                        uint2 *seg = p.cand + (long long)(q0 + rl) * p.cap + (long long)(p.nt_base + nt) * TILE;
+                        // What a survivor costs is its STORE INSTRUCTION (the CU's store path takes ~10-18 cycles per
+                        // instruction however few lanes it carries: tools/ablation/c1_epilogue_ab.sh), so the first survivor
+                        // of every lane goes out in ONE instruction per row group instead of one per column block; a lane
+                        // with more than one survivor (rare below ~5 % of the elements passing) stores the rest behind it.
+                        // One slot request (returning LDS atomic) per lane.
+                        const bool h0 = colok[0] && acc[i][0][r] >= t, h1 = colok[1] && acc[i][1][r] >= t;
+                        const bool h2 = colok[2] && acc[i][2][r] >= t, h3 = colok[3] && acc[i][3][r] >= t;
+                        const unsigned c = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
+                        if (c) {
+                            uint2 *seg = p.cand + (long long)(q0 + rl) * p.cap + (long long)(p.nt_base + nt) * TILE;
+                            const int j1 = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+                            const float v1 = h0 ? acc[i][0][r] : h1 ? acc[i][1][r] : h2 ? acc[i][2][r] : acc[i][3][r];
+                            unsigned slot = atomicAdd(lcnt + rl, c);
+                            seg[slot] = make_uint2(__float_as_uint(v1), (unsigned)(col_base + j1 * 16));
+                            if (c > 1u) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = acc[i][j][r];
-                            if (colok[j] && v >= t)
-                                seg[atomicAdd(lcnt + rl, 1u)] = make_uint2(__float_as_uint(v), (unsigned)(col_base + j * 16));
+                                for (int j = 1; j < 4; ++j) {
+                                    const bool hj = j == 1 ? h1 : j == 2 ? h2 : h3;
+                                    if (hj && j != j1) seg[++slot] = make_uint2(__float_as_uint(acc[i][j][r]), (unsigned)(col_base + j * 16));
+                                }
+                            }
                         }
                     }
                 }
