@@ -13,7 +13,7 @@ def main(root, needle):
     rows = []
     for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            if needle in r["Kernel_Name"]:
+            if needle in r["Kernel_Name"] and "false, true>" not in r["Kernel_Name"]:      # not the (empty) fallback launches
                 rows.append((int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
     if not rows:
         print("no dispatches matched")

@@ -17,7 +17,8 @@ def mean_of(root, counter):
     vals = []
     for path in glob.glob(f"{root}/{counter}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            if "sim_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            # the launches bench.py times: bootstrap + filter launches (not the speculation fallback's empty ones)
+            if "sim_kernel" in r["Kernel_Name"] and "false, true>" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
