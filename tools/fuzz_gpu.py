@@ -95,4 +95,6 @@ def run(cases=40, seed=0, verbose=True):
 
 
 if __name__ == "__main__":
+    if os.environ.get("FUZZ_FORCE_FALLBACK"):           # every n-th query row through the speculation's exact fallback
+        ica._lib.check(ica._lib.lib().mi_debug_force_fallback(int(os.environ["FUZZ_FORCE_FALLBACK"])), "mi_debug_force_fallback")
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
