@@ -569,8 +569,8 @@ hipError_t launch_walk(int dtype, const mi::SimParams &p_in, hipStream_t s)
     const dim3 grid((unsigned)(ceil_div(nwg, 8) * 8));
     // the query tile (ksteps x 32 KiB) stays resident in LDS.  (The variant that streams both operands, for rows of
     // 257 .. 512 bytes, measured 3 % SLOWER than sim_kernel.h at f32 D = 128 and is not instantiated.)
-    if (dtype == MI_BF16) hipLaunchKernelGGL((mi::sim_walk_kernel<mi::DT_BF16, true>), grid, dim3(mi::SIM_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((mi::sim_walk_kernel<mi::DT_F32, true>), grid, dim3(mi::SIM_THREADS), 0, s, p);
+    if (dtype == MI_BF16) hipLaunchKernelGGL((mi::sim_walk_kernel<mi::DT_BF16>), grid, dim3(mi::SIM_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((mi::sim_walk_kernel<mi::DT_F32>), grid, dim3(mi::SIM_THREADS), 0, s, p);
     return hipGetLastError();
 }
 constexpr int WALK_MAX_KSTEPS = 2;      // rows of at most 256 bytes: bf16 D <= 128, f32 D <= 64

@@ -1,5 +1,5 @@
-// sim_walk_kernel.h -- the filter stage of the similarity kernel for SHORT rows (at most 512 bytes: D <= 256 bf16,
-// D <= 128 f32 -- the reference's own feature_dim = 128, track_ssl/moco.py:38), gfx950.
+// sim_walk_kernel.h -- the filter stage of the similarity kernel for SHORT rows (at most 256 bytes: D <= 128 bf16 -- the
+// reference's own feature_dim = 128, track_ssl/moco.py:38 -- or D <= 64 f32), gfx950.
 //
 // sim_kernel.h computes one 256 x 256 tile per workgroup.  With 2 .. 4 K-steps per tile the tile's fixed costs -- set-up,
 // the first operand stage that nothing overlaps, the hand-over of the CU to the next workgroup -- are as long as its K loop
@@ -7,9 +7,9 @@
 // its 256-row query tile and WALKS a run of bank tiles:
 //   * the operand stream never stops at a tile boundary: the K-step that ends tile j stages the first K-step of tile j + 1,
 //     so there is no prologue and no seam per tile, only the filter epilogue;
-//   * QRES (rows of at most 256 bytes: bf16 D <= 128, f32 D <= 64): the query tile is staged ONCE and stays resident in LDS
-//     (2 x 32 KiB), only bank K-steps are streamed (double buffered, 2 x 32 KiB): half the LDS-DMA traffic of a tile;
-//     otherwise both operands are streamed through the same two 64 KiB stages as in sim_kernel.h.
+//   * the query tile is staged ONCE and stays resident in LDS (2 x 32 KiB); only bank K-steps are streamed (double buffered,
+//     2 x 32 KiB): half the LDS-DMA traffic of a tile.  (A variant that streams both operands, for rows of 257 .. 512 bytes,
+//     measured 3 % SLOWER than sim_kernel.h at f32 D = 128 and was dropped: DESIGN.md 5.3.)
 // Everything that defines a result is unchanged: the same LDS image and swizzle, the same MFMA sequence per output element
 // (f32: one k-ascending chain), the same threshold filter and candidate hand-off (sim_kernel.h, MODE_FILTER) -- a similarity
 // does not depend on which kernel computed it (tests: fp32 bit-exact sweeps over D = 32 .. 160).
@@ -22,7 +22,7 @@
 
 namespace mi {
 
-template <int DT, bool QRES>
+template <int DT>
 __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[SIM_LDS_BYTES + SIM_EXTRA_LDS];
@@ -43,10 +43,9 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
 
-    // LDS regions (bytes from smem): QRES: query K-step t at t * 32 KiB, bank buffer b at 64 KiB + b * 32 KiB;
-    // otherwise stage b = [A 32 KiB][B 32 KiB] at b * 64 KiB
-    auto a_off = [&](int t, int buf) { return QRES ? t * OPERAND_TILE_BYTES : buf * STAGE_BYTES; };
-    auto b_off = [&](int buf) { return QRES ? 2 * OPERAND_TILE_BYTES + buf * OPERAND_TILE_BYTES : buf * STAGE_BYTES + OPERAND_TILE_BYTES; };
+    // LDS regions (bytes from smem): query K-step t at t * 32 KiB (t < 2), bank buffer b at 64 KiB + b * 32 KiB
+    auto a_off = [&](int t) { return t * OPERAND_TILE_BYTES; };
+    auto b_off = [&](int buf) { return 2 * OPERAND_TILE_BYTES + buf * OPERAND_TILE_BYTES; };
 
     // ---- LDS-DMA sources (as sim_kernel.h): wave w stages row groups 4w .. 4w+3 (8 rows each) of an operand tile; lane ->
     // (row r = 8g + lane/8, LDS chunk slot lane%8), source chunk = slot ^ swz(r).  The addresses are recomputed per piece
@@ -73,16 +72,13 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
     // stage piece i of K-step (bank tile s_nt, K-step st) into buffer `buf`
     int s_nt = nt_lo, s_t = 0;                                       // cursor: the next K-step to stage
     auto stage_piece = [&](int i, int buf) {
-        if constexpr (!QRES) dma(src_of(p.q, p.ldq_bytes, q0, p.B, i, s_t), a_off(0, buf) + w * 4096 + i * 1024);
         dma(src_of(p.x, p.ldx_bytes, p.col0 + s_nt * TILE, p.N, i, s_t), b_off(buf) + w * 4096 + i * 1024);
     };
 
     // ---- prologue (once per workgroup): the resident query tile, the first bank K-step, thresholds, counters
-    if constexpr (QRES) {
-        for (int t = 0; t < p.ksteps; ++t)
+    for (int t = 0; t < p.ksteps; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dma(src_of(p.q, p.ldq_bytes, q0, p.B, i, t), a_off(t, 0) + w * 4096 + i * 1024);
-    }
+        for (int i = 0; i < 4; ++i) dma(src_of(p.q, p.ldq_bytes, q0, p.B, i, t), a_off(t) + w * 4096 + i * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage_piece(i, 0);
     auto advance = [&]() {                                           // cursor -> the K-step after the one just staged
@@ -205,7 +201,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < p.ksteps; ++t) {
-            kstep(smem + a_off(t, buf), smem + b_off(buf), buf ^ 1);
+            kstep(smem + a_off(t), smem + b_off(buf), buf ^ 1);
             advance();
             buf ^= 1;
         }
