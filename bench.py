@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--data", choices=["random", "clustered", "clustered-sorted"], default="random",
                     help="random: N(0,1) rows, L2-normalised (the metric's workload).  clustered: class centroid + 0.5 N(0,1) "
                          "(SURVEY 8d realism variant); clustered-sorted: the same with the bank in class order (an ImageFolder memo loader)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on a one-GPU box: run the multi-rank code path (RCCL process group, candidate all-to-all, "
+                         "merge, label all-gather, barriers, max-over-ranks) with a process group of ONE rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -158,6 +161,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist_on = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         if torch.cuda.device_count() < world:
             raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
@@ -215,7 +225,7 @@ def main():
             return emulated_rank_step()
         if by_rows:
             knn = sharded.ShardedKnn(bank_rows, lo, compute_dtype=args.dtype, query_chunk=args.query_chunk or None,
-                                     shard_sizes=shard_sizes)
+                                     shard_sizes=shard_sizes, always_exchange=args.force_dist)
         else:
             knn = sharded.QuerySlicedKnn(bank_rows, compute_dtype=args.dtype, query_chunk=args.query_chunk or 16384)
         top1 = knn.predict(feature, labels, C, k, T, gather="top1")
@@ -224,7 +234,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     _lib.profile_enable(True)
@@ -232,14 +242,14 @@ def main():
     for _ in range(args.steps):
         pred, ranking = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sim_ms, sim_launches, sim_flops = _lib.profile_collect(0)
     sel_ms, sel_launches, _ = _lib.profile_collect(1)
     _lib.profile_enable(False)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -262,7 +272,7 @@ def main():
         ok = st[:, 1] > 0
         if bool(ok.any()):
             clock_ghz = float((st[ok, 0] / st[ok, 1]).median()) * 0.1
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     if rank == 0:
@@ -294,9 +304,10 @@ def main():
             "config": {
                 "workload": f"BASELINE configs[3]: kNN monitor, {B} queries x {N}x{D} bank, k={k}, T={T}, "
                             f"{C} classes, {args.dtype} MFMA with fp32 accumulate; step = pack + fused sim/top-k"
-                            f"{' + RCCL candidate all-to-all + merge' if world > 1 and by_rows else ''} + vote + ranking",
+                            f"{' + RCCL candidate all-to-all + merge' if dist_on and by_rows else ''} + vote + ranking",
                 "queries": B, "bank_rows": N, "dim": D, "k": k, "classes": C,
-                "ranks": dist.get_world_size() if world > 1 else 1,      # size of the process group that did the work
+                "ranks": dist.get_world_size() if dist_on else 1,        # size of the process group that did the work
+                **({"rehearsal": "--force-dist: multi-rank code path on a one-rank RCCL group"} if args.force_dist else {}),
                 **({"emulated_rank_of": emu, "rank_bank_rows": hi - lo} if emu else {}),
                 "parallelism": (f"bank rows sharded over {world} GPU(s); merge/vote sharded by query slice; top-1 labels all-gathered"
                                 if by_rows else
@@ -321,7 +332,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(feature, bank_rows, labels, args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

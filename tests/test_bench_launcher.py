@@ -51,3 +51,18 @@ def test_gpus_2_starts_two_ranks_and_relays_their_status():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_path_on_a_one_rank_rccl_group():
+    """`bench.py --force-dist`: the code a rank of an N-GPU job runs -- RCCL process group, candidate all-to-all, merge,
+    top-1 all-gather, barriers, max-over-ranks -- on a process group of ONE rank (two RCCL ranks cannot share the box's
+    one GPU), on a small workload; the JSON line must come out complete."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--queries", "3000", "--bank", "60000",
+                        "--dim", "256", "--classes", "100", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-clock-probe"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["ranks"] == 1 and "rehearsal" in line["config"] and line["n_gpus"] == 1
+    assert line["value"] > 0 and line["roofline"]["launches"] > 0 and "all-to-all" in line["config"]["workload"]
