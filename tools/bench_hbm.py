@@ -66,6 +66,12 @@ def main():
     ci = torch.randint(0, Nl, (G, Bm, k), generator=g, device=dev)
     t = timed(lambda: ica.knn_merge(cv, ci, k))
     line("merge_wave_kernel (shard merge)", G * Bm * k * 12 + Bm * k * 12, t, f"G={G} B={Bm} k={k}")
+    # ... and at the shape ONE rank of an 8-rank C4 step merges: its 1/8 slice of a 50 000-query chunk (sharded.py)
+    Bm = 6250
+    cv = torch.rand((G, Bm, k), generator=g, device=dev).sort(dim=2, descending=True).values
+    ci = torch.randint(0, Nl, (G, Bm, k), generator=g, device=dev)
+    t = timed(lambda: ica.knn_merge(cv, ci, k))
+    line("merge_wave_kernel (one rank's slice at G=8, C4)", G * Bm * k * 12 + Bm * k * 12, t, f"G={G} B={Bm} k={k}")
     # MoCo queue: truncating ring push (memory_bank.py:65-72) and StorageBank scatter (:32)
     mb = ica.MemoryBank()
     mb.register("negative", dim=128, k=65536)

@@ -2,7 +2,9 @@
 """Randomised shape fuzz on one GPU: mi_knn_topk (fp32, bit-exact vs the chain oracle; bf16 against float64 products of the
 bf16-rounded inputs under a rounding bound; clustered cases also with the
 bank sorted so that a query meets all its neighbours in one stage) and mi_knn_vote on the result under random labels
-(scores within 1e-5, ranking a permutation, descending, ties to the lower class).  usage: tools/fuzz_gpu.py [cases] [seed]"""
+(scores within 1e-5 for k <= 256, ranking a permutation, descending, ties to the lower class).
+usage: tools/fuzz_gpu.py [cases] [seed]; FUZZ_ONLY=<case> re-runs one case of a seed with diagnostics;
+FUZZ_FORCE_FALLBACK=<n> sends every n-th query row through the speculation's exact fallback"""
 import os
 import sys
 import time
@@ -21,6 +23,7 @@ def run(cases=40, seed=0, verbose=True):
     """Returns the number of cases checked; raises AssertionError on the first mismatch."""
     rs = np.random.RandomState(seed)
     t0 = time.time()
+    only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None      # re-run one case of a seed
     for c in range(cases):
         B = int(rs.choice([1, 3, 64, 255, 256, 257, 700, 1500]))
         N = int(rs.choice([1, 7, 255, 2047, 2048, 2049, 2304, 5000, 12289, 40000, 70001]))
@@ -40,10 +43,20 @@ def run(cases=40, seed=0, verbose=True):
         f = ko.l2_normalize(f) if style != "ascending" else f.astype(np.float32)
         x = ko.l2_normalize(x) if style != "ascending" else x.astype(np.float32)
         f, x = np.ascontiguousarray(f, np.float32), np.ascontiguousarray(x, np.float32)
+        if only is not None and c != only:              # replay the generator's draws of a passing case, run nothing
+            rs.randint(0, int(rs.choice([1, 2, 10, 100, 1000, 2048, 5000])), size=N)
+            continue
         sim = chain.sim_chain_f32(f, x)
         v_ref, i_ref = chain.topk_rows(sim, k)
         v, i = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(x).cuda(), "fp32"), k)
         ok = np.array_equal(v.cpu().numpy(), v_ref) and np.array_equal(i.cpu().numpy(), i_ref)
+        why = "fp32 top-k"
+        if not ok and only is not None:
+            vv, ii = v.cpu().numpy(), i.cpu().numpy()
+            bad = np.nonzero((vv != v_ref).any(1) | (ii != i_ref).any(1))[0]
+            print("rows that differ:", bad[:20], "of", B)
+            r0 = int(bad[0]); cols = np.nonzero((vv[r0] != v_ref[r0]) | (ii[r0] != i_ref[r0]))[0]
+            print("row", r0, "first differing positions", cols[:10], "got", vv[r0][cols[:6]], ii[r0][cols[:6]], "want", v_ref[r0][cols[:6]], i_ref[r0][cols[:6]])
         # sorted banks: every query meets all its neighbours in one stage (class-ordered memo loader)
         if ok and style == "clustered" and N > 4096:
             order = np.argsort(-(x @ x[0]), kind="stable")
@@ -51,14 +64,27 @@ def run(cases=40, seed=0, verbose=True):
             v_ref2, i_ref2 = chain.topk_rows(chain.sim_chain_f32(f, xs), k)
             v2, i2 = ica.knn_topk(torch.from_numpy(f).cuda(), ica.BankIndex.from_rows(torch.from_numpy(xs).cuda(), "fp32"), k)
             ok = np.array_equal(v2.cpu().numpy(), v_ref2) and np.array_equal(i2.cpu().numpy(), i_ref2)
+            why = "fp32 top-k, sorted bank"
         # vote + ranking of this case's neighbours under random labels (wave-per-row kernel for k <= 256, C <= 2048)
         if ok:
             C = int(rs.choice([1, 2, 10, 100, 1000, 2048, 5000]))
             lab = rs.randint(0, C, size=N)
+            why = f"vote C={C}"
             rank, scores = ica.knn_vote(v, i, torch.from_numpy(lab).cuda(), C, 0.1, return_scores=True)
             s_ref = ko.vote_scores(ko.vote_weights(v_ref, 0.1), lab[i_ref], C)
             sc, rk = scores.cpu().numpy(), rank.cpu().numpy()
-            ok = bool(np.all(np.isclose(sc, s_ref, rtol=1e-5, atol=1e-30)))            # inf == inf (unnormalised 'ascending' rows overflow exp)
+            # 1e-5 relative up to k = 256 (the reference votes with k = 200); beyond it the tolerance grows with k as the
+            # rounding bound of a k-term float32 sum does: both sides add in neighbour order, but their expf differ in the
+            # last ulp, and over several hundred EQUAL weights that flips the sum's rounding drift (seed 31 case 647:
+            # 600 identical weights in one class, 1.8e-5 apart, each 1e-5 from the exact sum)
+            rtol = 1e-5 * max(1.0, k / 256.0)
+            ok = bool(np.all(np.isclose(sc, s_ref, rtol=rtol, atol=1e-30)))            # inf == inf (unnormalised 'ascending' rows overflow exp)
+            if not ok and only is not None:
+                rel = np.abs(sc - s_ref) / np.maximum(np.abs(s_ref), 1e-30)
+                r0, c0 = np.unravel_index(np.argmax(rel), rel.shape)
+                print("vote scores: max rel diff", rel.max(), "at", (r0, c0), "got", sc[r0, c0], "want", s_ref[r0, c0],
+                      "rows off:", int((rel > rtol).any(1).sum()), "of", B)
+                print("row's values:", v_ref[r0][:8], "...", v_ref[r0][-4:], "distinct:", len(np.unique(v_ref[r0])))
             ok = ok and np.array_equal(np.sort(rk, axis=1), np.tile(np.arange(C), (B, 1)))
             srt = np.take_along_axis(sc, rk, axis=1)
             ok = ok and bool(np.all(srt[:, 1:] <= srt[:, :-1]))
@@ -69,6 +95,7 @@ def run(cases=40, seed=0, verbose=True):
         # returned rows, descending with lower rows first among equals, and the returned set = the reference set except
         # for rows within tol of the k-th value
         if ok and style != "ascending":
+            why = "bf16 top-k"
             fb = torch.from_numpy(f).to(torch.bfloat16).to(torch.float64).numpy()
             xb = torch.from_numpy(x).to(torch.bfloat16).to(torch.float64).numpy()
             ref = fb @ xb.T
@@ -87,7 +114,7 @@ def run(cases=40, seed=0, verbose=True):
             np.put_along_axis(hit, ib, True, axis=1)
             ok = ok and bool(np.all(hit[must]))
         if verbose:
-            print(f"case {c:3d} B={B:5d} N={N:6d} D={D:4d} k={k:5d} {style:10s} {'ok' if ok else 'MISMATCH'}", flush=True)
+            print(f"case {c:3d} B={B:5d} N={N:6d} D={D:4d} k={k:5d} {style:10s} {'ok' if ok else 'MISMATCH in ' + why}", flush=True)
         assert ok, f"fuzz case {c} (seed {seed}): B={B} N={N} D={D} k={k} {style}"
     if verbose:
         print(f"{cases} cases: fp32 top-k bit-exact, bf16 top-k within the rounding bound, vote within 1e-5, in {time.time() - t0:.1f} s")
