@@ -483,10 +483,15 @@ Plan make_plan(int64_t B, int64_t N, int k, int64_t cand_bytes, int64_t bank_row
 //   then: n = seen / 4, at least one launch: ~k ln 1.25 = 0.22 k candidates per row and stage (within the
 //         wave-per-row merge's 64) and O(log N) refreshes instead of one per launch;
 //   always <= cap: the candidate buffer holds the worst case of one stage (every element passes).
+// With the speculative first threshold (spec_rank) the ramp is not needed: that threshold already passes only
+// ~spec_rank * n / S elements of a stage, so the first stage runs straight to one cache-fit launch -- a bank that fits one
+// (C1: 50 000 rows) is ONE filter launch and ONE refresh instead of three of each (C1 bf16 0.55 -> 0.53 ms, one box; the
+// 1.28 M-row bank and its 1/2 ... 1/8 shards: +-0.1 %).
 constexpr int LATE_GROWTH_DIV = 4;
-int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t left)      // left: bank rows not filtered yet
+constexpr int RAMP_SAFE = 3, RAMP_SPEC = 63;
+int64_t next_stage_cols(const Plan &pl, int64_t seen, int64_t left, int ramp)      // left: bank rows not filtered yet
 {
-    int64_t n = 3 * seen / STAGE_QUANTUM * STAGE_QUANTUM;
+    int64_t n = ramp * seen / STAGE_QUANTUM * STAGE_QUANTUM;
     if (n < pl.min_cols) n = pl.min_cols;
     if (n > pl.launch_cols) {
         n = seen / LATE_GROWTH_DIV / pl.launch_cols * pl.launch_cols;      // whole launches
@@ -551,14 +556,17 @@ int compute_units()
     return n;
 }
 
-hipError_t launch_walk(int dtype, const mi::SimParams &p_in, hipStream_t s)
+hipError_t launch_walk(int dtype, const mi::SimParams &p_in, bool compact, hipStream_t s)
 {
     mi::SimParams p = p_in;
+    p.walk_compact = compact ? 1 : 0;
     const int cus = compute_units();
-    // tiles per run: the run length that minimises rounds x (run + ~1.5 tiles of per-workgroup set-up)
+    // tiles per run: the run length that minimises rounds x (run + ~1.5 tiles of per-workgroup set-up); a compacted run's
+    // count has to fit cnt2's 16 bits
     double best = 1e30;
-    int best_tp = p.ntiles;
-    for (int tp = p.ntiles; tp >= 1; --tp) {
+    const int tp_max = p.ntiles < 255 ? p.ntiles : 255;
+    int best_tp = tp_max;
+    for (int tp = tp_max; tp >= 1; --tp) {
         const int64_t nwg = (int64_t)p.qtiles * ceil_div(p.ntiles, tp);
         const double cost = (double)ceil_div(nwg, cus) * (tp + 1.5);
         if (cost < best) { best = cost; best_tp = tp; }
@@ -836,7 +844,8 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
     sel.big_stride = big_stride(pl.B_pad);
     for (int stage = 0; col < N; ++stage) {
         sel.parity = stage & 1;
-        const int64_t ncols = next_stage_cols(pl, col + (sampled ? pl.s0_cols : 0), N - col);   // the sample counts as "seen"
+        const int64_t ncols = next_stage_cols(pl, col + (sampled ? pl.s0_cols : 0), N - col,      // the sample counts as "seen"
+                                              spec ? RAMP_SPEC : RAMP_SAFE);
         sel.ntiles = (int)ceil_div(ncols, mi::TILE);
         for (int64_t off = 0; off < ncols; off += pl.launch_cols) {          // launch_cols is a whole number of tiles
             const int64_t lc = ncols - off < pl.launch_cols ? ncols - off : pl.launch_cols;
@@ -845,7 +854,7 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
             sp.ntiles = (int)ceil_div(lc, mi::TILE);
             sp.nt_base = (int)(off / mi::TILE);
             ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)lc * (double)D, s);
-            if (sp.ksteps <= WALK_MAX_KSTEPS) HIP_CHECK(launch_walk(dtype, sp, s));
+            if (sp.ksteps <= WALK_MAX_KSTEPS) HIP_CHECK(launch_walk(dtype, sp, k <= mi::WSEL_MAX_K, s));
             else HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
         }
         col += ncols;

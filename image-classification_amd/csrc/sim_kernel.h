@@ -74,6 +74,10 @@ struct SimParams {
     unsigned *zero_word;      // MODE_LSE: a word the NEXT kernel on the stream expects to be 0 (its arrival counter)
     // sim_walk_kernel.h only: workgroup v of qtiles * walk_nsplit walks bank tiles [split * walk_tps, (split + 1) * walk_tps)
     int walk_nsplit, walk_tps;
+    // ... and, when set, hands over the survivors of a row's WHOLE RUN as one list: slots counted on from the run's first
+    // tile's segment (the segments of a run are contiguous), one cnt2 entry (<= 255 tiles x 256 fits its 16 bits) and one
+    // mask bit per (row, run).  Only for the consumer that takes a list of any length: bag_refresh_kernel (k <= 256).
+    int walk_compact;
     // FB instantiation only (the exact fallback of a speculative first threshold, mi_knn.hip): the launch's query rows
     // are the COMPACT rows c = 0 .. n - 1 of the failed-row list, n = *fb_cnt - fb_base; compact row c is query row
     // fb_rows[fb_base + c] and filters with that row's SAFE sample threshold fb_tau0[...]; workgroups beyond n exit at once

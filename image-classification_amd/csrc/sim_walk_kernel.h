@@ -192,7 +192,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the resident query tile, the first bank K-step; thresholds
     __syncthreads();
 
-    unsigned *lcnt = (unsigned *)(smem + SIM_LDS_BYTES + 1024);   // [256] zero at the start of every tile's epilogue
+    unsigned *lcnt = (unsigned *)(smem + SIM_LDS_BYTES + 1024);   // [256] survivors per row: of the tile, or of the run so far (walk_compact)
     const float *ltau = (const float *)(smem + SIM_LDS_BYTES);    // [256]
     int buf = 0;
     for (int nt = nt_lo; nt < nt_hi; ++nt) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
                         const bool h2 = colok[2] && acc[i][2][r] >= t, h3 = colok[3] && acc[i][3][r] >= t;
                         const unsigned c = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
                         if (c) {
-                            uint2 *seg = p.cand + (long long)(q0e + rl) * p.cap + (long long)(p.nt_base + nt) * TILE;
+                            uint2 *seg = p.cand + (long long)(q0e + rl) * p.cap + (long long)(p.nt_base + (p.walk_compact ? nt_lo : nt)) * TILE;
                             const int j1 = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
                             const float v1 = h0 ? acc[i][0][r] : h1 ? acc[i][1][r] : h2 ? acc[i][2][r] : acc[i][3][r];
                             unsigned slot = atomicAdd(lcnt + rl, c);
@@ -253,13 +253,18 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
                 }
             }
         }
-        __syncthreads();
-        if (tid < TILE) {
-            const unsigned n = lcnt[tid];
-            lcnt[tid] = 0u;                                                          // for the next tile (its K-steps' barriers publish it)
-            const int st = p.nt_base + nt;                                           // tile of the stage
-            p.cnt2[(long long)st * p.bpad + q0e + tid] = (unsigned short)n;
-            if (n) atomicOr(p.tmask + (long long)(q0e + tid) * p.mask_words + (st >> 5), 1u << (st & 31));
+        // publish the counts: per tile, or once for the run (walk_compact: the counters run on through the tiles, whose
+        // K-steps' barriers order the epilogues' atomics; the refresh then reads a row's survivors of the run as ONE list
+        // instead of one short segment per tile -- at C1 four entries each)
+        if (!p.walk_compact || nt + 1 == nt_hi) {
+            __syncthreads();
+            if (tid < TILE) {
+                const unsigned n = lcnt[tid];
+                lcnt[tid] = 0u;                                                      // for the next tile (its K-steps' barriers publish it)
+                const int st = p.nt_base + (p.walk_compact ? nt_lo : nt);            // tile of the stage
+                p.cnt2[(long long)st * p.bpad + q0e + tid] = (unsigned short)n;
+                if (n) atomicOr(p.tmask + (long long)(q0e + tid) * p.mask_words + (st >> 5), 1u << (st & 31));
+            }
         }
     }
 }

@@ -203,6 +203,25 @@ def test_all_ties_pick_lowest_indices(ica):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_every_element_survives_long_runs_of_short_rows(ica, dtype):
+    """Short rows (D = 64: the walk kernel) hand over a row's survivors of a whole RUN of bank tiles as one list.  Here
+    every element of the bank passes every threshold (all similarities tie at 2.0, exact in both dtypes), so each list is
+    as long as it can get -- run x 256 entries, far beyond one tile's 256 and one refresh batch -- and the k real
+    neighbours (similarity 4.0) sit at the very end of the bank, behind all of them."""
+    D, N, B, k, hi = 64, 60000, 2100, 200, 300
+    x = np.full((N, D), 0.125, np.float32)
+    x[N - hi:] = 0.25
+    f = np.full((B, D), 0.25, np.float32)
+    v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), dtype), k)
+    assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(N - hi, N - hi + k), (B, 1)))
+    assert np.all(v.cpu().numpy() == np.float32(4.0))
+    # ... and with nothing above the ties: the lowest rows win
+    v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x[:N - hi]), dtype), k)
+    assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(k), (B, 1)))
+    assert np.all(v.cpu().numpy() == np.float32(2.0))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_unwritten_query_rows_of_the_storage_bank(ica, dtype):
     """``StorageBank.register`` fills ``test_feature`` with +inf (memory_bank.py:16-18) and ``knn_test`` hands the
     whole buffer to ``knn_predict`` (ssltrainer.py:184): a row no ``test_step`` has written is all +inf.  Its
