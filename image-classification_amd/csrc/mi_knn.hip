@@ -1013,9 +1013,12 @@ int mi_knn_merge(const float *cand_val, const int64_t *cand_idx, int G, int64_t 
     sel.k = k;
     sel.out_val = out_val;
     sel.out_idx = (long long *)out_idx;
-    if (k <= mi::WSEL_MAX_K && (int64_t)G * kc <= 64 * mi::MERGE_WAVE_SLOTS)      // every configuration of the sharded monitor (k = 200, G <= 8)
-        hipLaunchKernelGGL(mi::merge_wave_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, sel);
-    else
+    if (k <= mi::WSEL_MAX_K && (int64_t)G * kc <= 64 * mi::MERGE_WAVE_SLOTS) {    // every configuration of the sharded monitor (k = 200, G <= 8)
+        if ((int64_t)G * kc <= 64 * mi::MERGE_WAVE_SLOTS_SMALL)
+            hipLaunchKernelGGL((mi::merge_wave_kernel<mi::MERGE_WAVE_SLOTS_SMALL, 4>), dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, sel);
+        else
+            hipLaunchKernelGGL((mi::merge_wave_kernel<mi::MERGE_WAVE_SLOTS, 3>), dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, sel);
+    } else
         hipLaunchKernelGGL((mi::select_kernel<mi::SRC_GATHER>), dim3((unsigned)B), dim3(mi::SEL_THREADS), 0, (hipStream_t)stream, sel);
     HIP_CHECK(hipGetLastError());
     return MI_OK;

@@ -1220,32 +1220,44 @@ __global__ __launch_bounds__(256, 6) void bag_refresh_kernel(const SelectParams 
 // through 2 KiB of wave-private LDS, sorted once by the register network and written out.  Replaces the
 // workgroup-per-row LDS radix select + bitonic sort (select_kernel<SRC_GATHER>: 41 us / 1.07 TB/s per 2048 rows at G = 8),
 // which stays for larger k or more candidates.  Keys are distinct (global rows are); ties in value go to the lower row.
-constexpr int MERGE_WAVE_SLOTS = 32;
-__global__ __launch_bounds__(256) void merge_wave_kernel(const SelectParams p)
+// Two instantiations: 26 slots (<= 1664 candidates: 8 shards x k = 200) at four waves per SIMD, 32 slots at three -- the
+// kernel is latency bound, and the 32-slot form does not fit 128 registers without spilling.
+constexpr int MERGE_WAVE_SLOTS = 32, MERGE_WAVE_SLOTS_SMALL = 26;
+template <int SLOTS, int MIN_WGS>
+__global__ __launch_bounds__(256, MIN_WGS) void merge_wave_kernel(const SelectParams p)
 {
+    static_assert(SLOTS <= 32, "one 32-bit slot mask per lane");
     __shared__ unsigned long long bag_all[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wv;
     if (row >= p.B) return;
     unsigned long long *bag = bag_all[wv];
     const int k = p.k, total = p.G * p.kc;
-    unsigned hi[MERGE_WAVE_SLOTS], lo[MERGE_WAVE_SLOTS], w[MERGE_WAVE_SLOTS];
+    unsigned hi[SLOTS], lo[SLOTS], w[32];                                  // w: the bit-sliced working copy (32 x 32 transpose)
     unsigned a = ~0u, o = 0u, act = 0u;
+    // candidate j = s2 * 64 + lane is entry c = j % kc of shard g = j / kc: element ((g * B + row) * kc + c) of the
+    // [G, B, kc] blocks.  (c, element) are carried from slot to slot -- one division per lane instead of one per slot
+    int c = lane % p.kc;
+    long long e = ((long long)(lane / p.kc) * p.B + row) * p.kc + c;
+    const int dc = 64 % p.kc;
+    const long long de = (long long)(64 / p.kc) * p.B * p.kc + dc, wrap = (long long)(p.B - 1) * p.kc;
 #pragma unroll
-    for (int s2 = 0; s2 < MERGE_WAVE_SLOTS; ++s2) {
+    for (int s2 = 0; s2 < SLOTS; ++s2) {
         const int j = s2 * 64 + lane;
         unsigned long long key = 0ull;
         if (j < total) {
-            const int g = j / p.kc, c = j - g * p.kc;
-            const long long e = ((long long)g * p.B + row) * p.kc + c;
             const long long gi = p.g_idx[e];
             if (gi >= 0) key = make_key(p.g_val[e], (unsigned)gi);          // padding (-1) and NaN: not a candidate
         }
+        c += dc;
+        e += de;
+        if (c >= p.kc) { c -= p.kc; e += wrap; }
         hi[s2] = (unsigned)(key >> 32);
         lo[s2] = (unsigned)key;
-        w[s2] = hi[s2];
         if (key) { a &= hi[s2]; o |= hi[s2]; act |= 0x80000000u >> s2; }      // slot c lives at bit 31 - c
     }
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) w[s2] = s2 < SLOTS ? hi[s2 < SLOTS ? s2 : 0] : 0u;
     const int nz = (int)wave_sum_u32((unsigned)__popc(act));
     const int keep = nz < k ? nz : k;
     unsigned long long kth = 1ull;                                          // fewer than k real keys: keep every one
@@ -1272,9 +1284,9 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const SelectParams p)
         // ... then, among the slots that hold exactly that value, by the row word (0xFFFFFFFF - row: lower row = larger)
         unsigned al = ~0u, ol = 0u;
 #pragma unroll
-        for (int s2 = 0; s2 < MERGE_WAVE_SLOTS; ++s2) {
-            w[s2] = lo[s2];
-            if (in & (0x80000000u >> s2)) { al &= lo[s2]; ol |= lo[s2]; }
+        for (int s2 = 0; s2 < 32; ++s2) {
+            w[s2] = s2 < SLOTS ? lo[s2 < SLOTS ? s2 : 0] : 0u;
+            if (s2 < SLOTS && (in & (0x80000000u >> s2))) { al &= w[s2]; ol |= w[s2]; }
         }
         al = wave_and_u32(al);
         ol = wave_or_u32(ol);
@@ -1289,13 +1301,15 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const SelectParams p)
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     int base = 0;
 #pragma unroll
-    for (int s2 = 0; s2 < MERGE_WAVE_SLOTS; ++s2) {
-        const unsigned long long key = ((unsigned long long)hi[s2] << 32) | lo[s2];
-        const bool take = key >= kth && key != 0ull;
-        const unsigned long long bal = __ballot(take);
-        const int at = base + __popcll(bal & ltmask);
-        if (take && at < 256) bag[at] = key;
-        base += __popcll(bal);
+    for (int s2 = 0; s2 < SLOTS; ++s2) {
+        if (s2 * 64 < total) {                                              // slots beyond the candidates hold nothing (uniform)
+            const unsigned long long key = ((unsigned long long)hi[s2] << 32) | lo[s2];
+            const bool take = key >= kth && key != 0ull;
+            const unsigned long long bal = __ballot(take);
+            const int at = base + __popcll(bal & ltmask);
+            if (take && at < 256) bag[at] = key;
+            base += __popcll(bal);
+        }
     }
     wave_step();
     unsigned long long k4[4];

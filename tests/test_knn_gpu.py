@@ -325,6 +325,27 @@ def test_index_base_and_merge_equals_unsharded(ica):
         assert np.array_equal(v.cpu().numpy(), vo) and np.array_equal(i.cpu().numpy(), io)
 
 
+@pytest.mark.parametrize("G,kc,k", [(8, 200, 200), (8, 256, 256), (7, 256, 200), (3, 5, 9), (2, 64, 1), (1, 200, 200), (4, 300, 300)])
+def test_merge_kernel_vs_oracle(ica, G, kc, k):
+    """``mi_knn_merge`` on synthetic candidate blocks against ``oracle.merge_topk``: both wave-per-row instantiations
+    (<= 1664 and <= 2048 candidates per row), the workgroup kernel beyond them (k = 300), values that tie across shards
+    (the lower global row wins), the k-th value itself shared by several rows, padding entries (index -1)."""
+    rs = np.random.RandomState(G * 1000 + kc)
+    B, n_local = 133, 5000
+    vals = np.round(rs.rand(G, B, kc).astype(np.float32) * 64) / 64          # 65 distinct values: masses of ties
+    vals[:, 5] = 0.5                                                          # one row where EVERY candidate ties
+    vals = -np.sort(-vals, axis=2)
+    idx = np.stack([g * n_local + np.stack([rs.permutation(n_local)[:kc] for _ in range(B)]) for g in range(G)]).astype(np.int64)
+    # within equal values a shard lists the lower row first (what mi_knn_topk emits)
+    order = np.lexsort((idx, -vals), axis=2)
+    vals, idx = np.take_along_axis(vals, order, 2), np.take_along_axis(idx, order, 2)
+    if kc > 4 and G * (kc - 2) >= k:
+        vals[0, 7, kc - 2:], idx[0, 7, kc - 2:] = -np.inf, -1                # a shard that held fewer than kc rows
+    v, i = ica.knn_merge(dev(vals), dev(idx), k)
+    vo, io = ko.merge_topk(vals, idx, k)
+    assert np.array_equal(v.cpu().numpy(), vo) and np.array_equal(i.cpu().numpy(), io)
+
+
 @pytest.mark.parametrize("chunk", [256, 300, 4096])
 def test_chunked_driver_equals_single_call(ica, chunk):
     """ShardedKnn (world 1): the query-chunked driver gives the single-call result bit for bit."""
