@@ -1029,7 +1029,10 @@ int mi_kth_largest(const float *x, int64_t n, int64_t k, float *out, mi_stream_t
     if (!x || !out) return fail(MI_ERR_ARG, "mi_kth_largest: null pointer");
     if (n < 1 || n > INT32_MAX) return fail(MI_ERR_ARG, "mi_kth_largest: n=%lld outside [1, 2^31)", (long long)n);
     if (k < 1 || k > n) return fail(MI_ERR_ARG, "mi_kth_largest: selected index k out of range (k=%lld, n=%lld)", (long long)k, (long long)n);
-    hipLaunchKernelGGL(mi::kth_largest_kernel, dim3(1), dim3(mi::KTH_THREADS), 0, (hipStream_t)stream, x, (long long)n, (long long)k, out);
+    if (n <= mi::KTH_REG_MAX_N && ((uintptr_t)x & 15u) == 0)      // 16-byte loads
+        hipLaunchKernelGGL(mi::kth_largest_reg_kernel, dim3(1), dim3(mi::KTH_THREADS), 0, (hipStream_t)stream, x, (int)n, (int)k, out);
+    else
+        hipLaunchKernelGGL(mi::kth_largest_kernel, dim3(1), dim3(mi::KTH_THREADS), 0, (hipStream_t)stream, x, (long long)n, (long long)k, out);
     HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

@@ -1373,4 +1373,90 @@ __global__ __launch_bounds__(KTH_THREADS) void kth_largest_kernel(const float *_
     if (tid == 0) out[0] = s_prefix == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : from_orderable(s_prefix);
 }
 
+// The same selection for a bank of at most 65 536 values (the CHMatch queues hold 50 000) with the bank IN REGISTERS: one
+// workgroup of 1024 threads, 64 consecutive values per thread, read once, then an MSB-first binary radix select on bit-sliced
+// keys as sample_tau_kernel's -- two 32 x 32 bit transposes per thread, after which a radix step is two v_and + two v_bcnt,
+// a wave sum, one LDS word per wave and ONE workgroup barrier -- only over the bits in which the keys differ at all.  No
+// LDS atomics (the 8-bit histogram of kth_largest_kernel serialises on them when the values share their high bits, as
+// confidences in [0, 1] do: 68-75 us for 50 000 values), no second pass over memory.
+constexpr int KTH_REG_MAX_N = 64 * KTH_THREADS;
+__global__ __launch_bounds__(KTH_THREADS) void kth_largest_reg_kernel(const float *__restrict__ x, int n, int k, float *__restrict__ out)
+{
+    __shared__ unsigned s_part[2][KTH_THREADS / 64];
+    __shared__ unsigned s_ao[2][KTH_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned w0[32], w1[32];                                   // slots 0..31 and 32..63: element tid * 64 + slot
+    unsigned in0 = 0u, in1 = 0u, a = ~0u, o = 0u;
+    // A thread owns 64 CONSECUTIVE values (256 bytes: sixteen 16-byte loads off one base address with immediate offsets --
+    // a slot-major mapping needs 64 separate 64-bit addresses and spills).  One half at a time (load, convert, transpose).
+    const int base = tid * 64;
+#define MI_KTH_LOAD_HALF(WW, IN, C0)                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                                 \
+        const int i0 = base + (C0) + q * 4;                                                                         \
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
+        if (i0 + 3 < n) v = *(const float4 *)(x + i0);                                                              \
+        else {                                                      /* the one thread that holds the end of the bank */ \
+            if (i0 < n) v.x = x[i0];                                                                                \
+            if (i0 + 1 < n) v.y = x[i0 + 1];                                                                        \
+            if (i0 + 2 < n) v.z = x[i0 + 2];                                                                        \
+        }                                                                                                           \
+        const float f[4] = {v.x, v.y, v.z, v.w};                                                                    \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                             \
+            unsigned key = 0u;                                                                                      \
+            if (i0 + u < n) {                                                                                       \
+                key = (f[u] != f[u]) ? 0xFFFFFFFFu : orderable_f32(f[u]);   /* NaNs order above +inf, as torch.topk does */ \
+                a &= key;                                                                                           \
+                o |= key;                                                                                           \
+                IN |= 0x80000000u >> (q * 4 + u);                   /* slot c lives at bit 31 - c */                \
+            }                                                                                                       \
+            WW[q * 4 + u] = key;                                                                                     \
+        }                                                                                                           \
+    }                                                                                                               \
+    bit_transpose32(WW);                                            /* w[31 - b] = bit b of every slot */
+    MI_KTH_LOAD_HALF(w0, in0, 0)
+    // the first half is DONE here (opaque copies): left to itself the compiler sinks both transposes behind the reduction
+    // below and interleaves them, which needs more than the 128 registers of a 1024-thread workgroup
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(w0[i]));
+    MI_KTH_LOAD_HALF(w1, in1, 32)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(w1[i]));
+#undef MI_KTH_LOAD_HALF
+    // the bits in which the keys differ at all
+    a = wave_and_u32(a);
+    o = wave_or_u32(o);
+    if (lane == 0) { s_ao[0][wv] = a; s_ao[1][wv] = o; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KTH_THREADS / 64; ++i) { a &= s_ao[0][i]; o |= s_ao[1][i]; }
+    const unsigned var = (unsigned)__builtin_amdgcn_readfirstlane((int)(a ^ o));
+    unsigned res = (unsigned)__builtin_amdgcn_readfirstlane((int)a) & ~var;
+    int r = k, step = 0;
+#pragma unroll
+    for (int b = 31; b >= 0; --b) {
+        if (!(var & (1u << b))) continue;                      // workgroup-uniform: scalar branch
+        const unsigned ones0 = in0 & w0[31 - b], ones1 = in1 & w1[31 - b];
+        const unsigned c = wave_sum_u32((unsigned)(__popc(ones0) + __popc(ones1)));
+        unsigned *part = s_part[step & 1];                     // two buffers, one barrier per step: a wave two steps ahead has passed the barrier every reader of this buffer arrives at first
+        ++step;
+        if (lane == 0) part[wv] = c;
+        __syncthreads();
+        int cnt1 = 0;
+#pragma unroll
+        for (int i = 0; i < KTH_THREADS / 64; ++i) cnt1 += (int)part[i];
+        cnt1 = __builtin_amdgcn_readfirstlane(cnt1);
+        if (cnt1 >= r) {                                       // the r-th largest has the bit set: the zeros drop out
+            in0 = ones0;
+            in1 = ones1;
+            res |= 1u << b;
+        } else {                                               // it has the bit clear: the ones drop out
+            r -= cnt1;
+            in0 ^= ones0;                                      // = in & ~w, without a second copy of w (the compiler kept 64 of them, and spilled)
+            in1 ^= ones1;
+        }
+    }
+    if (tid == 0) out[0] = res == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : from_orderable(res);
+}
+
+
 }  // namespace mi

@@ -61,6 +61,32 @@ def test_hip_kth_edge_cases():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 4097, 50000, 65535, 65536, 65537, 200001])
+def test_hip_kth_sizes_and_value_ranges(n):
+    """Both kernels (bank in registers up to 65 536 values, the histogram passes beyond, and for a view that is not 16-byte
+    aligned) against the oracle: confidences in [0, 1) (keys that share their high bits), signed values, few distinct
+    values (masses of duplicates), values with NaN / +-inf / +-0 mixed in; k at both ends, around the middle, at 0.8 n."""
+    import image_classification_amd as ica
+    rs = np.random.RandomState(n)
+    banks = {
+        "unit": rs.rand(n).astype(np.float32),
+        "signed": (rs.randn(n) * 1e3).astype(np.float32),
+        "dups": rs.randint(0, 7, size=n).astype(np.float32) / 4 - 0.5,
+        "special": np.where(rs.rand(n) < 0.05, rs.choice([np.nan, np.inf, -np.inf, 0.0, -0.0], size=n), rs.randn(n)).astype(np.float32),
+    }
+    ks = sorted({1, n, max(1, n // 2), max(1, int(0.8 * n)), min(n, 2), max(1, n - 1)})
+    for name, bank in banks.items():
+        ref_sorted = torch.from_numpy(bank).topk(n).values.numpy()                       # torch: NaN first, then descending
+        t = torch.from_numpy(np.concatenate([[7.0], bank]).astype(np.float32)).cuda()    # t[1:] starts 4 bytes off a 16-byte boundary
+        aligned, shifted = t[1:].clone(), t[1:]
+        for k in ks:
+            want = ref_sorted[k - 1]
+            for view in (aligned, shifted):
+                got = ica.kth_largest(view, k).item()
+                assert (np.isnan(got) and np.isnan(want)) or got == want, (name, n, k, got, want)
+
+
+@pytest.mark.gpu
 def test_hip_neighbor_label_agreement_vs_oracle():
     """betacs_v2.py:159-162 with the fused top-k at k = 10 (cosine definition: parity unpinned, see neighbors.py)."""
     import image_classification_amd as ica
