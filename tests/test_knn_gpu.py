@@ -202,23 +202,26 @@ def test_all_ties_pick_lowest_indices(ica):
         assert np.all(v.cpu().numpy() == np.float32(D * 0.125 * 0.25))
 
 
+@pytest.mark.parametrize("D,N,B", [(64, 60000, 2100), (32, 40000, 20000)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_every_element_survives_long_runs_of_short_rows(ica, dtype):
+def test_every_element_survives_long_runs_of_short_rows(ica, dtype, D, N, B):
     """Short rows (D = 64: the walk kernel) hand over a row's survivors of a whole RUN of bank tiles as one list.  Here
     every element of the bank passes every threshold (all similarities tie at 2.0, exact in both dtypes), so each list is
     as long as it can get -- run x 256 entries, far beyond one tile's 256 and one refresh batch -- and the k real
-    neighbours (similarity 4.0) sit at the very end of the bank, behind all of them."""
-    D, N, B, k, hi = 64, 60000, 2100, 200, 300
+    neighbours (twice that similarity) sit at the very end of the bank, behind all of them.  The second shape has 79 query
+    tiles, so a workgroup's run is as long as the bank slice of a launch (one run per row)."""
+    k, hi = 200, 300
     x = np.full((N, D), 0.125, np.float32)
     x[N - hi:] = 0.25
     f = np.full((B, D), 0.25, np.float32)
+    lo_sim, hi_sim = np.float32(D * 0.125 * 0.25), np.float32(D * 0.25 * 0.25)
     v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x), dtype), k)
-    assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(N - hi, N - hi + k), (B, 1)))
-    assert np.all(v.cpu().numpy() == np.float32(4.0))
+    assert torch.equal(i, torch.arange(N - hi, N - hi + k, device=i.device).expand(B, k))
+    assert bool((v == float(hi_sim)).all())
     # ... and with nothing above the ties: the lowest rows win
     v, i = ica.knn_topk(dev(f), ica.BankIndex.from_rows(dev(x[:N - hi]), dtype), k)
-    assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(k), (B, 1)))
-    assert np.all(v.cpu().numpy() == np.float32(2.0))
+    assert torch.equal(i, torch.arange(k, device=i.device).expand(B, k))
+    assert bool((v == float(lo_sim)).all())
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
