@@ -1,4 +1,6 @@
 set -o pipefail
+# usage (GPU box): tools/trace_shard.sh -- rocprofv3 kernel trace of ONE rank of the 8-rank C4 job emulated on one GPU (bench.py --emulate-rank-of 8);
+# prints the last step kernel by kernel (duration, idle gap in front) -> profiles/r03_shard8_trace.txt
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/g8
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/g8 -o r -- python3 $R/bench.py --emulate-rank-of 8 --no-cpu-baseline --no-clock-probe --steps 3 --warmup 2 > $R/gpurun_out/g8/line.json 2> $R/gpurun_out/g8/err.txt || { tail -5 $R/gpurun_out/g8/err.txt; exit 1; }
