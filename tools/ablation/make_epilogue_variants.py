@@ -6,7 +6,12 @@ hand-off removed, to apportion what a candidate costs in the candidate-dense ear
     nohit     the hit test is kept, hits do nothing
     nomask    as built, but the per-row tile bitmask is not updated (no global atomicOr)
     nocnt     as built, but neither the per-tile counts nor the tile bitmask are written
-usage: python tools/ablation/make_epilogue_variants.py   -> image-classification_amd/libmi_knn_{noatomic,nostore,nohit}.so"""
+usage: python tools/ablation/make_epilogue_variants.py   -> image-classification_amd/libmi_knn_{noatomic,nostore,nohit}.so
+
+These are the arms behind DESIGN.md 5.3 (1) and apply to the epilogue as it was when they were measured: one slot request
+and one store per survivor and column block, i.e. the tree of `git checkout e739797~1`.  From e739797 on the first survivor
+of every lane of a row group goes out in one store instruction (what these arms found) and the anchors below no longer
+exist: run this from a checkout of that parent commit."""
 import os
 import shutil
 import subprocess
@@ -30,7 +35,9 @@ for name, new in NEW.items():
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(d, "include"))
         p = os.path.join(d, "pkg", "csrc", "sim_kernel.h")
         s = open(p).read()
-        assert s.count(OLD) == 1 and s.count(MASK_OLD) == 1 and s.count(CNT_OLD) == 1
+        if not (s.count(OLD) == 1 and s.count(MASK_OLD) == 1 and s.count(CNT_OLD) == 1):
+            raise SystemExit("make_epilogue_variants.py: the per-survivor epilogue these arms patch is not in this tree "
+                             "(it was replaced in e739797): run from `git checkout e739797~1`")
         if name == "nomask":
             s = s.replace(MASK_OLD, "asm volatile(\"\" :: \"v\"(n));")
         elif name == "nocnt":
