@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on a one-GPU box: run the multi-rank code path (RCCL process group, candidate all-to-all, "
                          "merge, label all-gather, barriers, max-over-ranks) with a process group of ONE rank")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="REHEARSAL ONLY (not a measurement): with --gpus N > 1 every rank uses cuda:0 and the process group is gloo "
+                         "(RCCL refuses two ranks on one device) -- runs the N-rank launcher, step loop, exchange and timing code on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -159,8 +162,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist_on = world > 1 or args.force_dist
     if args.force_dist and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -169,9 +173,12 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
-        if torch.cuda.device_count() < world:
-            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
+            dist.init_process_group("nccl", device_id=device)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
@@ -250,7 +257,7 @@ def main():
     sel_ms, sel_launches, _ = _lib.profile_collect(1)
     _lib.profile_enable(False)
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert ranking.shape[1] == C and (emu or tuple(pred.shape) == (B,))   # top-1 everywhere, full ranking with the slice owner
@@ -308,6 +315,8 @@ def main():
                 "queries": B, "bank_rows": N, "dim": D, "k": k, "classes": C,
                 "ranks": dist.get_world_size() if dist_on else 1,        # size of the process group that did the work
                 **({"rehearsal": "--force-dist: multi-rank code path on a one-rank RCCL group"} if args.force_dist else {}),
+                **({"rehearsal": f"--rehearse-shared-gpu: {world} ranks on ONE GPU over gloo; not a measurement"}
+                   if args.rehearse_shared_gpu and world > 1 else {}),
                 **({"emulated_rank_of": emu, "rank_bank_rows": hi - lo} if emu else {}),
                 "parallelism": (f"bank rows sharded over {world} GPU(s); merge/vote sharded by query slice; top-1 labels all-gathered"
                                 if by_rows else

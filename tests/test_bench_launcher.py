@@ -66,3 +66,21 @@ def test_bench_multi_rank_code_path_on_a_one_rank_rccl_group():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["config"]["ranks"] == 1 and "rehearsal" in line["config"] and line["n_gpus"] == 1
     assert line["value"] > 0 and line["roofline"]["launches"] > 0 and "all-to-all" in line["config"]["workload"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_n_ranks_sharing_the_one_gpu(n):
+    """`python bench.py --gpus N --rehearse-shared-gpu`: the PLAIN command starts its N ranks itself; every rank runs the
+    multi-rank step loop (row shards, candidate exchange, merge + vote of its query slice, top-1 all-gather, barriers,
+    max-over-ranks, the clock-probe steps with their collectives) on cuda:0 over gloo, since RCCL refuses two ranks on one
+    device.  A rehearsal of the code path the 8-GPU run takes, not a measurement: rank 0's line must come out complete
+    and say so, and every rank must exit cleanly (no rank-0-only collective, no deadlock: the timeout is the check)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rehearse-shared-gpu", "--queries", "3000",
+                        "--bank", "60001", "--dim", "256", "--classes", "100", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["config"]["ranks"] == n and "not a measurement" in line["config"]["rehearsal"]
+    assert line["value"] > 0 and line["roofline"]["launches"] > 0 and line["scaling"] == "strong"
