@@ -854,7 +854,7 @@ int knn_topk_impl(const void *q, int64_t ldq, const void *bank, int64_t ldb, int
             sp.ntiles = (int)ceil_div(lc, mi::TILE);
             sp.nt_base = (int)(off / mi::TILE);
             ProfScope ps(MI_PROF_SIM, 2.0 * (double)B * (double)lc * (double)D, s);
-            if (sp.ksteps <= WALK_MAX_KSTEPS) HIP_CHECK(launch_walk(dtype, sp, k <= mi::WSEL_MAX_K, s));
+            if (sp.ksteps <= WALK_MAX_KSTEPS && sp.cap < (1 << 24)) HIP_CHECK(launch_walk(dtype, sp, k <= mi::WSEL_MAX_K, s));   // (24-bit segment offsets)
             else HIP_CHECK((launch_sim_dt<mi::MODE_FILTER>(dtype, sp, s)));
         }
         col += ncols;

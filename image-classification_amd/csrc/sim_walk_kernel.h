@@ -94,7 +94,8 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
     const int a_row_off = (wm * 128 + lr) * KSTEP_BYTES;
     const int b_row_off = (wn * 64 + lr) * KSTEP_BYTES;
     if (tid < TILE) {
-        ((float *)(smem + SIM_LDS_BYTES))[tid] = p.tau[q0 + tid];
+        // rows past B (padding of the last query tile) get a NaN threshold: nothing compares >= NaN, so the epilogue needs no row test
+        ((float *)(smem + SIM_LDS_BYTES))[tid] = (q0 + tid) < p.B ? p.tau[q0 + tid] : __builtin_nanf("");
         ((unsigned *)(smem + SIM_LDS_BYTES + 1024))[tid] = 0u;
     }
 
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
         asm volatile("" : "+s"(q0e));
         int row_l = wm * 128 + lq * 4;                        // same for the lane's first row within the tile (LDS counter addresses)
         asm volatile("" : "+v"(row_l));
+        uint2 *seg_base = p.cand + (long long)q0e * p.cap + (long long)(p.nt_base + (p.walk_compact ? nt_lo : nt)) * TILE;
         bool colok[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) colok[j] = (col_base + j * 16) < col_end;
@@ -224,22 +226,27 @@ __global__ __launch_bounds__(SIM_THREADS, 2) void sim_walk_kernel(const SimParam
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float t = tau_i[r];
-                const float m = fmaxf(fmaxf(acc[i][0][r], acc[i][1][r]), fmaxf(acc[i][2][r], acc[i][3][r]));
-                if (__any(m >= t)) {
-                    const int rl = row_l + i * 16 + r;                    // row within the tile
-                    if (q0e + rl < p.B) {
+                // four compares whose masks the slow path uses again, OR-ed on the scalar side -- not max3 + max + compare (fmaxf
+                // also costs a canonicalising v_max x, x per operand pair): the epilogue is VALU-issue bound at D = 128
+                // (1190 VALU instructions per wave and tile beside 128 MFMAs: tools/pmc_c1.sh).  NaNs never pass.
+                const bool g0 = acc[i][0][r] >= t, g1 = acc[i][1][r] >= t, g2 = acc[i][2][r] >= t, g3 = acc[i][3][r] >= t;
+                if (__any(g0 || g1 || g2 || g3)) {
+                    const int rl = row_l + i * 16 + r;                    // row within the tile (a padding row's threshold is NaN: never here)
+                    {
                         // What a survivor costs is its STORE INSTRUCTION (the CU's store path takes ~10-18 cycles per
                         // instruction however few lanes it carries), so the first survivor of every lane goes out in ONE
                         // instruction per row group instead of one per column block; a lane with more than one survivor
                         // (rare below ~5 % of the elements passing) stores the rest behind it.  One slot request per lane.
-                        const bool h0 = colok[0] && acc[i][0][r] >= t, h1 = colok[1] && acc[i][1][r] >= t;
-                        const bool h2 = colok[2] && acc[i][2][r] >= t, h3 = colok[3] && acc[i][3][r] >= t;
+                        const bool h0 = colok[0] && g0, h1 = colok[1] && g1, h2 = colok[2] && g2, h3 = colok[3] && g3;
                         const unsigned c = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
                         if (c) {
-                            uint2 *seg = p.cand + (long long)(q0e + rl) * p.cap + (long long)(p.nt_base + (p.walk_compact ? nt_lo : nt)) * TILE;
+                            // segment of (row, tile or run): a wave-uniform base + a 32-bit element offset (rl < 256, cap < 2^24:
+                            // the host checks) -- a 24-bit multiply and one 64-bit add per row group instead of a 64-bit multiply
+                            const unsigned seg_off = __umul24((unsigned)rl, (unsigned)p.cap);
                             const int j1 = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
-                            const float v1 = h0 ? acc[i][0][r] : h1 ? acc[i][1][r] : h2 ? acc[i][2][r] : acc[i][3][r];
+                            uint2 *seg = seg_base + seg_off;
                             unsigned slot = atomicAdd(lcnt + rl, c);
+                            const float v1 = h0 ? acc[i][0][r] : h1 ? acc[i][1][r] : h2 ? acc[i][2][r] : acc[i][3][r];
                             seg[slot] = make_uint2(__float_as_uint(v1), (unsigned)(col_base + j1 * 16));
                             if (c > 1u) {
 #pragma unroll
