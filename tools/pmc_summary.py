@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection CSVs: for kernels whose name contains <needle>, restricted to the
-dispatches with the largest grid (the full-size filter stages), the mean of each counter per dispatch."""
+dispatches of the grid size with the largest mean counter values (the full-size filter stages), the mean of each counter per dispatch."""
 import csv
 import glob
 import sys
@@ -18,7 +18,12 @@ def main(root, needle):
     if not rows:
         print("no dispatches matched")
         return
-    big = max(g for g, _, _ in rows)
+    # the grid that did the work: largest mean counter value per dispatch (an empty fallback launch can have the larger grid)
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for g, _, v in rows:
+        tot[g] += v
+        cnt[g] += 1
+    big = max(tot, key=lambda g: tot[g] / cnt[g])
     acc = defaultdict(list)
     for g, n, v in rows:
         if g == big:
